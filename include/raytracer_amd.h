@@ -1,0 +1,230 @@
+/*
+ * raytracer_amd.h — C-ABI of the MI355X render hot path.
+ *
+ * This is the drop-in boundary for the reference's `render()` free function
+ * (reference src/raytracer.cpp:422-463) and everything below it: `trace()`
+ * (src/raytracer.cpp:279-420), `Camera::castRays` (src/camera.h:57-79) and
+ * `Primitive::intersect` for Sphere / Plane / Triangle / Model
+ * (src/primitives.cpp:11-25, 42-126, 173-203, 364-384).
+ *
+ * The reference has no plugin/FFI layer; its seam is the C++ call
+ *   render(img, x_start, y_start, cH, cW, camera, scene, background, finPix, thread_count)
+ * The host surface (raytracer_amd/host/raytracer.hpp) keeps that signature and
+ * flattens Scene + Camera into the plain structs below before calling in here.
+ *
+ * Plain pointers and sizes only; no C++ or torch types. All functions return
+ * RT_OK (0) or a negative rt_status; rt_last_error() gives the message.
+ */
+#ifndef RAYTRACER_AMD_H
+#define RAYTRACER_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,    /* bad argument / malformed flat scene            */
+    RT_ERR_DEVICE = -2,     /* HIP runtime error (message has hipGetErrorString) */
+    RT_ERR_NO_DEVICE = -3,  /* no usable gfx950 device                         */
+    RT_ERR_OVERFLOW = -4,   /* bounce queues could not be sized (internal)     */
+    RT_ERR_LIMIT = -5       /* size above a stated maximum                     */
+} rt_status;
+
+/* Material: reference src/material.h:13-47 (same fields, bools as int32). */
+typedef struct rt_material {
+    float color[3];
+    float ka, kd, ks;
+    float kr, kt;
+    float specRefExp;
+    float refractiveIdx;
+    int32_t reflective;
+    int32_t refractive;
+} rt_material;
+
+/* Light: reference src/scene.h:15-27. color already multiplied by `factor` (src/scene.cpp:121). */
+typedef struct rt_light {
+    float pos[3];
+    float color[3];
+} rt_light;
+
+/* Sphere: reference src/primitives.h:107-119. */
+typedef struct rt_sphere {
+    float center[3];
+    float radius;
+} rt_sphere;
+
+/* Plane: reference src/primitives.h:31-62; (a,b,c) is the stored, already normalised normal. */
+typedef struct rt_plane {
+    float a, b, c, d;
+} rt_plane;
+
+/* Model: reference src/primitives.h:121-159. Faces [first_face, first_face+num_faces) of the
+ * triangle arrays, in the Model's own face order; bb_* is Model::bbvol as the host computed it
+ * (src/primitives.cpp:205-236) — the gate of Model::intersect (src/primitives.cpp:370) uses it as is. */
+typedef struct rt_model {
+    uint32_t first_face;
+    uint32_t num_faces;
+    float bb_center[3];
+    float bb_radius;
+} rt_model;
+
+enum { RT_OBJ_SPHERE = 0, RT_OBJ_PLANE = 1, RT_OBJ_MODEL = 2 };
+
+/* One entry of Scene::objects, in scene order (the tie-break of src/raytracer.cpp:292-300
+ * depends on this order). `index` selects spheres[]/planes[]/models[] by `type`;
+ * `material` indexes materials[] (a Model's hits carry the Model's material, src/raytracer.cpp:307). */
+typedef struct rt_object {
+    int32_t type;
+    uint32_t index;
+    uint32_t material;
+    uint32_t reserved;
+} rt_object;
+
+/* Flattened scene, host memory, read only during rt_scene_create. Triangle data is SoA:
+ * six arrays of n_faces*3 floats (Triangle::v0,v1,v2,n0,n1,n2, src/primitives.h:65). */
+typedef struct rt_flat_scene {
+    const rt_object* objects;     uint32_t n_objects;
+    const rt_sphere* spheres;     uint32_t n_spheres;
+    const rt_plane* planes;       uint32_t n_planes;
+    const rt_model* models;       uint32_t n_models;
+    const rt_material* materials; uint32_t n_materials;
+    const rt_light* lights;       uint32_t n_lights;
+    const float* v0; const float* v1; const float* v2;
+    const float* n0; const float* n1; const float* n2;
+    uint32_t n_faces;
+} rt_flat_scene;
+
+/* Camera state after construction/rotate/move: reference src/camera.h:14-37 (fields are private there;
+ * the host surface exposes them). up/at are the normalised members, right = cross(at, up). */
+typedef struct rt_camera {
+    float eye[3];
+    float up[3];
+    float right[3];
+    float at[3];
+    float aspectRatio;
+    float fov;            /* degrees */
+    uint32_t imWidth;
+    uint32_t imHeight;
+} rt_camera;
+
+#define RT_MAX_AA_POINTS 255
+
+/* Everything the reference fixes at compile time in main()/file scope (src/raytracer.cpp:74,286,677;
+ * src/camera.h:40-55; src/common.h:36). */
+typedef struct rt_params {
+    float background[3];      /* src/raytracer.cpp:677 */
+    int32_t max_depth;        /* MAX_DEPTH, src/raytracer.cpp:74 (reference: 10) */
+    uint32_t n_aa;            /* anti-aliasing pattern size; rays per pixel = 1 + n_aa (src/camera.h:72-79) */
+    const float* aa_xy;       /* n_aa (x,y) pairs */
+} rt_params;
+
+/* Per-call counters. Rays are counted as SURVEY.md §8(d) defines them. */
+typedef struct rt_stats {
+    uint64_t trace_calls;     /* primary + reflection + refraction trace() invocations */
+    uint64_t shadow_rays;     /* one per light per shaded hit                          */
+    uint64_t level_rays[16];  /* trace() invocations per recursion level               */
+    uint32_t passes;          /* image passes the frame was split into                 */
+    uint32_t retries;         /* passes re-run with a smaller size after queue overflow */
+    float    kernel_ms;       /* HIP-event time of all kernels of this call            */
+    float    trace_kernel_ms; /* of which: the trace_level kernels                     */
+    uint32_t trace_launches;  /* number of trace_level launches                        */
+    uint32_t reserved;
+} rt_stats;
+
+typedef struct rt_scene rt_scene;   /* opaque; owns the HBM copy of the scene on one device */
+
+/* Replaces: Scene ownership of objects/lights (reference src/scene.h:29-39) on the device side.
+ * Builds the BVH on the host (one per Model) and uploads the SoA scene to `device`. */
+int rt_scene_create(const rt_flat_scene* scene, int device, rt_scene** out);
+void rt_scene_destroy(rt_scene* scene);
+
+/* Replaces: render() (reference src/raytracer.cpp:422-463) for the rectangle [x0,x0+w) x [y0,y0+h).
+ * bgr_out is a caller-owned HOST buffer laid out as the reference's img (BGR8, interleaved,
+ * row-major over the FULL image: byte 3*(y*imWidth+x), src/raytracer.cpp:434,446-448);
+ * only the rectangle's bytes are written. stats may be NULL. */
+int rt_render(rt_scene* scene, const rt_camera* cam, const rt_params* params,
+              uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
+              uint8_t* bgr_out, rt_stats* stats);
+
+/* Same as rt_render but the framebuffer is a DEVICE pointer (same full-image BGR8 layout) and the call
+ * is asynchronous on `stream` (a hipStream_t, or NULL for the scene's own stream) unless stats != NULL.
+ * Replaces: render() when the caller keeps frames on the GPU (multi-GPU gather, encoders). */
+int rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_params* params,
+                     uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
+                     uint8_t* d_bgr_out, void* stream, rt_stats* stats);
+
+/* Multi-GPU tile ownership. Replaces: the tile decomposition of thread_render()
+ * (reference src/raytracer.cpp:577-627: fixed tiles handed to workers). The full image is cut into
+ * tile_w x tile_h tiles, numbered row-major; this call renders the tiles with
+ * (tile_index % n_parts == part) into d_tiles_out, a DEVICE buffer in tile-major order
+ * (k-th owned tile at byte k*tile_w*tile_h*3, pixels row-major inside the tile, BGR8; pixels of
+ * edge tiles outside the image are written as 0). rt_tiles_owned() gives k's range. */
+int rt_render_tiles_device(rt_scene* scene, const rt_camera* cam, const rt_params* params,
+                           uint32_t tile_w, uint32_t tile_h, uint32_t part, uint32_t n_parts,
+                           uint8_t* d_tiles_out, void* stream, rt_stats* stats);
+uint32_t rt_tiles_owned(uint32_t imWidth, uint32_t imHeight, uint32_t tile_w, uint32_t tile_h,
+                        uint32_t part, uint32_t n_parts);
+
+/* Scatter gathered tile-major buffers (parts concatenated in part order, each rt_tiles_owned() tiles)
+ * back into the reference's row-major BGR8 frame. d_tiles_all and d_bgr_out are device pointers.
+ * Replaces: the shared `img` all render() workers write into (reference src/raytracer.cpp:434). */
+int rt_untile_device(int device, uint32_t imWidth, uint32_t imHeight, uint32_t tile_w, uint32_t tile_h,
+                     uint32_t n_parts, const uint8_t* d_tiles_all, uint8_t* d_bgr_out, void* stream);
+
+/* Unit entry points used by the parity tests (each runs the same device functions the renderer uses). */
+
+/* Replaces: Camera::castRays (reference src/camera.h:72-79) for n pixels; rays_out gets
+ * n*(1+n_aa)*6 floats (origin xyz, direction xyz), host memory. */
+int rt_cast_rays(int device, const rt_camera* cam, const rt_params* params,
+                 const uint32_t* xy, uint32_t n_pixels, float* rays_out);
+
+/* Replaces: Primitive::intersect over scene objects (reference src/primitives.h:23) for n rays given
+ * as 6 floats each. object < 0: closest hit over the whole scene as trace() does
+ * (src/raytracer.cpp:292-300), hit_obj_out gets the object index or -1. object >= 0: that object only.
+ * dist_out/normal_out as intersect() leaves them on a hit (unspecified on a miss). */
+int rt_intersect(rt_scene* scene, int object, const float* rays, uint32_t n_rays,
+                 int32_t* hit_obj_out, float* dist_out, float* normal_out);
+
+/* Replaces: the shadow test of trace() (reference src/raytracer.cpp:318-325): occluded_out[i] = 1 if any
+ * object is hit with tmpdist < max_dist[i]. */
+int rt_occluded(rt_scene* scene, const float* rays, const float* max_dist, uint32_t n_rays,
+                uint8_t* occluded_out);
+
+/* Replaces: trace() (reference src/raytracer.cpp:279-420) for n rays at depth 0; rgb_out n*3 floats. */
+int rt_trace(rt_scene* scene, const rt_params* params, const float* rays, uint32_t n_rays,
+             float* rgb_out, rt_stats* stats);
+
+/* BVH introspection for tests and the roofline's algorithmic bytes/flops. */
+typedef struct rt_bvh_info {
+    uint32_t n_nodes;
+    uint32_t n_faces;
+    uint32_t max_depth;
+    uint32_t node_bytes;
+    uint32_t tri_bytes;
+    uint32_t reserved;
+    uint64_t device_bytes;   /* total HBM held by the scene */
+} rt_bvh_info;
+int rt_scene_bvh_info(const rt_scene* scene, rt_bvh_info* out);
+
+/* Traversal work of the last call that passed a non-NULL stats AND had counting enabled with
+ * rt_set_count_work(1): node visits / triangle tests / sphere / plane tests summed over all rays. */
+typedef struct rt_work {
+    uint64_t nodes_visited;
+    uint64_t tris_tested;
+    uint64_t spheres_tested;
+    uint64_t planes_tested;
+} rt_work;
+int rt_set_count_work(rt_scene* scene, int enable);
+int rt_get_work(const rt_scene* scene, rt_work* out);
+
+const char* rt_last_error(void);   /* thread-local message of the last failing call */
+const char* rt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAYTRACER_AMD_H */

@@ -1,0 +1,425 @@
+/*
+ * TEST INFRASTRUCTURE ONLY — the parity oracle. Nothing under raytracer_amd/ may include, link or call this.
+ *
+ * rt_oracle.c — plain-C CPU restatement of the reference's render hot path: brute force (no BVH), recursive,
+ * same float/double mix and operation order as the reference, statement by statement. Each function cites the
+ * reference lines it follows. Pinned bit for bit against the reference's own compiled objects
+ * (oracle/_ref/libref.so, built from /root/reference by oracle/Makefile) and against the golden vectors in
+ * tests/golden/ that were taken from them (tests/test_oracle_golden.py, tests/test_oracle_vs_ref.py).
+ *
+ * Build: gcc -O2 -ffp-contract=off -fopenmp -shared (oracle/Makefile). x86-64 baseline: SSE2 scalar IEEE
+ * arithmetic, no FMA, double where the reference's overload resolution picks double (sqrt/pow/tan/cos/sin of a
+ * float argument resolve to the C double functions under the reference's include set — verified with a
+ * static_assert probe).
+ *
+ * One place where the reference reads an indeterminate value is given a definition here (and in the HIP path):
+ * Sphere::intersect leaves `dist` untouched when neither branch at primitives.cpp:188-192 applies (a root is
+ * exactly 0, or NaN input); the caller's variable then holds whatever the previous intersect() left there.
+ * The flow of that variable through trace()'s loops is followed exactly; its first value (uninitialised in the
+ * reference, raytracer.cpp:285 / primitives.cpp:366) is defined as 0, which makes such a test a miss.
+ */
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "raytracer_amd.h"
+
+typedef struct { float x, y, z; } v3;
+typedef struct { v3 o, d; } ray_t;
+
+static const float EPS = 0.000001f; /* common.h:36 (constexpr Float) */
+
+static inline v3 V(float x, float y, float z) { v3 r = {x, y, z}; return r; }
+static inline v3 vld(const float* p) { return V(p[0], p[1], p[2]); }
+static inline v3 vadd(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 vsub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 vmul(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
+static inline v3 vneg(v3 a) { return V(-a.x, -a.y, -a.z); }
+/* container.h:134-138 */
+static inline float vdot(v3 a, v3 b) { return (a.x * b.x) + (a.y * b.y) + (a.z * b.z); }
+/* container.h:140-142: sqrt resolves to the double function; narrowed on return */
+static inline float vlen(v3 a) { return (float)sqrt((double)vdot(a, a)); }
+/* container.h:144-146: multiply by the float quotient 1/length */
+static inline v3 vnormalize(v3 a) { return vmul(a, 1.0f / vlen(a)); }
+/* container.h:151-158 */
+static inline v3 vcross(v3 u, v3 v) {
+    return V(u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x);
+}
+static inline int visnan(v3 a) { return isnan(a.x) || isnan(a.y) || isnan(a.z); }
+/* std::max<Float>(a,b) = (a<b)?b:a ; std::min(a,b) = (b<a)?b:a */
+static inline float fmax_std(float a, float b) { return (a < b) ? b : a; }
+static inline float fmin_std(float a, float b) { return (b < a) ? b : a; }
+/* container.h:255 */
+static inline v3 ray_point(const ray_t* r, float dist) { return vadd(r->o, vmul(r->d, dist)); }
+
+/* ---- Sphere::intersect, primitives.cpp:173-196; getNormal :198-203 ---- */
+static int sphere_intersect(const rt_sphere* s, const ray_t* ray, float* dist, v3* normal) {
+    const v3 c = vld(s->center);
+    const v3 temp = vsub(ray->o, c);
+    const float val1 = vdot(temp, ray->d);
+    const float val2 = vlen(temp);
+    const float val3 = val1 * val1 - val2 * val2 + s->radius * s->radius;
+    if (val3 < 0) return 0;
+    /* `-val1 + sqrt(val3)`: sqrt is the double function, so the sum is formed in double and then narrowed */
+    const float dist1 = (float)((double)(-val1) + sqrt((double)val3));
+    const float dist2 = (float)((double)(-val1) - sqrt((double)val3));
+    if (dist1 < 0 || dist2 < 0) {
+        *dist = fmax_std(dist1, dist2);
+    } else if (dist1 > 0 && dist2 > 0) {
+        *dist = fmin_std(dist1, dist2);
+    } /* else: dist keeps the caller's value (see header) */
+    v3 n = vsub(ray_point(ray, *dist), c);
+    const float inv = (float)(1.0 / (double)s->radius); /* container.h:72-75: double reciprocal */
+    *normal = vmul(n, inv);
+    return *dist > EPS;
+}
+
+/* ---- Plane::intersect, primitives.cpp:11-25 (the two `false;` statements are no-ops) ---- */
+static int plane_intersect(const rt_plane* p, const ray_t* ray, float* dist, v3* normal) {
+    const v3 n = V(p->a, p->b, p->c);
+    *normal = n;
+    const float vd = vdot(n, ray->d);
+    const float vo = vdot(n, ray->o) + p->d;
+    *dist = -vo / vd;
+    return *dist > EPS;
+}
+
+/* ---- Triangle::intersect, Moeller-Trumbore branch, primitives.cpp:42-81,125 (CULLING == 0) ---- */
+static int triangle_intersect(const rt_flat_scene* sc, uint32_t f, const ray_t* ray, float* dist, v3* normal) {
+    const v3 v0 = vld(sc->v0 + 3 * (size_t)f), v1 = vld(sc->v1 + 3 * (size_t)f), v2 = vld(sc->v2 + 3 * (size_t)f);
+    *normal = vld(sc->n1 + 3 * (size_t)f);
+    const v3 v0v1 = vsub(v1, v0);
+    const v3 v0v2 = vsub(v2, v0);
+    const v3 pVec = vcross(ray->d, v0v2);
+    const float det = vdot(pVec, v0v1);
+    if (fabsf(det) < EPS) return 0;
+    const float invDet = 1 / det;
+    const v3 tVec = vsub(ray->o, v0);
+    const float u = invDet * vdot(pVec, tVec);
+    if (u < 0 || u > 1) return 0;
+    const v3 qVec = vcross(tVec, v0v1);
+    const float v = invDet * vdot(qVec, ray->d);
+    if (v < 0 || u + v > 1) return 0;
+    *dist = invDet * vdot(qVec, v0v2);
+    /* (1-u-v)*n0 + u*n1 + v*n2, not normalised (:80-81) */
+    const v3 n0 = vld(sc->n0 + 3 * (size_t)f), n1 = vld(sc->n1 + 3 * (size_t)f), n2 = vld(sc->n2 + 3 * (size_t)f);
+    *normal = vadd(vadd(vmul(n0, 1 - u - v), vmul(n1, u)), vmul(n2, v));
+    return *dist > EPS;
+}
+
+/* ---- Model::intersect, primitives.cpp:364-384 ---- */
+static int model_intersect(const rt_flat_scene* sc, const rt_model* m, const ray_t* ray, float* dist, v3* normal,
+                           uint64_t* tri_tests) {
+    float tmpdist = 0; /* uninitialised in the reference (:366) */
+    v3 tmpnormal = V(0, 0, 0);
+    *dist = FLT_MAX;
+    int hit = 0;
+    if (m->bb_radius >= 0) { /* bb_radius < 0: object without a gate (a lone Triangle in the scene) */
+        rt_sphere bb;
+        memcpy(bb.center, m->bb_center, sizeof bb.center);
+        bb.radius = m->bb_radius;
+        if (!sphere_intersect(&bb, ray, &tmpdist, &tmpnormal)) return 0;
+    }
+    for (uint32_t f = m->first_face; f < m->first_face + m->num_faces; ++f) {
+        if (triangle_intersect(sc, f, ray, &tmpdist, &tmpnormal) && tmpdist < *dist) {
+            *dist = tmpdist;
+            *normal = tmpnormal;
+            hit = 1;
+        }
+    }
+    if (tri_tests) *tri_tests += m->num_faces;
+    return hit && *dist > EPS;
+}
+
+static int object_intersect(const rt_flat_scene* sc, uint32_t k, const ray_t* ray, float* dist, v3* normal) {
+    const rt_object* o = &sc->objects[k];
+    switch (o->type) {
+        case RT_OBJ_SPHERE: return sphere_intersect(&sc->spheres[o->index], ray, dist, normal);
+        case RT_OBJ_PLANE: return plane_intersect(&sc->planes[o->index], ray, dist, normal);
+        default: return model_intersect(sc, &sc->models[o->index], ray, dist, normal, NULL);
+    }
+}
+
+typedef struct {
+    uint64_t trace_calls, shadow_rays;
+    uint64_t level_rays[16];
+} counters_t;
+
+/* ---- trace(), raytracer.cpp:279-420 ---- */
+static void trace(const rt_flat_scene* sc, const rt_params* prm, const ray_t* ray, int depth, float out[3],
+                  counters_t* cnt) {
+    float dist = FLT_MAX, tmpdist = 0; /* tmpdist uninitialised in the reference (:285) */
+    const float bias = 0.0001f;        /* :286 */
+    v3 tmpnormal = V(0, 0, 0), hitNormal = V(0, 0, 0);
+    int cur_obj = -1;
+    cnt->trace_calls++;
+    if (depth < 16) cnt->level_rays[depth]++;
+
+    for (uint32_t k = 0; k < sc->n_objects; ++k) { /* :292-300 */
+        if (object_intersect(sc, k, ray, &tmpdist, &tmpnormal)) {
+            if (tmpdist < dist) {
+                dist = tmpdist;
+                hitNormal = tmpnormal;
+                cur_obj = (int)k;
+            }
+        }
+    }
+    if (cur_obj < 0) { /* :302-304 */
+        out[0] = prm->background[0]; out[1] = prm->background[1]; out[2] = prm->background[2];
+        return;
+    }
+    float cr = 0, cg = 0, cb = 0; /* :306 */
+    const rt_material* mat = &sc->materials[sc->objects[cur_obj].material];
+    const v3 hitPt = ray_point(ray, dist);
+
+    for (uint32_t li = 0; li < sc->n_lights; ++li) { /* :311-345 */
+        const rt_light* l = &sc->lights[li];
+        v3 lv = vsub(vld(l->pos), hitPt);
+        const float ldist = vlen(lv);
+        lv = vnormalize(lv);
+        int inShadow = 0;
+        ray_t shadow_ray;
+        shadow_ray.o = vadd(hitPt, vmul(hitNormal, bias));
+        shadow_ray.d = lv;
+        cnt->shadow_rays++;
+        for (uint32_t k = 0; k < sc->n_objects; ++k) {
+            const int hit = object_intersect(sc, k, &shadow_ray, &tmpdist, &tmpnormal);
+            if (hit && tmpdist < ldist) { inShadow = 1; break; }
+        }
+        if (inShadow) continue;
+        if (visnan(hitNormal)) { out[0] = 1; out[1] = 0; out[2] = 0; return; } /* :330-332 */
+
+        /* diffuse :335-337: ((mat.color*l.color)*kd) * (cosPhi/(ldist*ldist)) */
+        const float cosPhi = fmax_std(vdot(hitNormal, lv), 0.0f);
+        const float fd = cosPhi / (ldist * ldist);
+        cr += ((mat->color[0] * l->color[0]) * mat->kd) * fd;
+        cg += ((mat->color[1] * l->color[1]) * mat->kd) * fd;
+        cb += ((mat->color[2] * l->color[2]) * mat->kd) * fd;
+        /* specular :340-343: R = (n*2)*(n.l) - l ; uses l, not the view vector; pow and the division in double */
+        const v3 reflectRay = vsub(vmul(vmul(hitNormal, 2.0f), vdot(hitNormal, lv)), lv);
+        const float cosAlpha = fmax_std(vdot(reflectRay, lv), 0.0f);
+        const float fs = (float)(pow((double)cosAlpha, (double)mat->specRefExp) / (double)(ldist * ldist));
+        cr += (l->color[0] * mat->ks) * fs;
+        cg += (l->color[1] * mat->ks) * fs;
+        cb += (l->color[2] * mat->ks) * fs;
+    }
+
+    ++depth; /* :347 */
+    v3 refractNormal = hitNormal;
+    float cosI = 0, cosT = 0, sinSqrPhit = 0, n1 = 0, n2 = 0, n = 0, rCoef = 0;
+    if (mat->refractive && depth <= prm->max_depth) { /* Fresnel :357-381 */
+        cosI = vdot(ray->d, hitNormal);
+        if (cosI < 0.0) {
+            n1 = 1.0f; n2 = mat->refractiveIdx; cosI = -cosI;
+        } else {
+            n1 = mat->refractiveIdx; n2 = 1.0f; refractNormal = vneg(refractNormal);
+        }
+        n = n1 / n2;
+        sinSqrPhit = n * n * (1 - cosI * cosI);
+        if (sinSqrPhit <= 1) {
+            cosT = (float)sqrt((double)(1 - sinSqrPhit));
+            const float Rorth = (n1 * cosI - n2 * cosT) / (n1 * cosI + n2 * cosT);
+            const float Rpar = (n2 * cosI - n1 * cosT) / (n2 * cosI + n1 * cosT);
+            rCoef = (Rorth * Rorth + Rpar * Rpar) / 2;
+        } else {
+            rCoef = 1;
+        }
+    }
+    float refl[3] = {0, 0, 0}, refr[3] = {0, 0, 0};
+    if (mat->reflective && depth <= prm->max_depth) { /* :385-388 */
+        ray_t r;
+        r.d = vadd(vmul(vmul(vneg(hitNormal), 2.0f), vdot(hitNormal, ray->d)), ray->d);
+        r.o = vadd(hitPt, vmul(hitNormal, bias));
+        float c[3];
+        trace(sc, prm, &r, depth, c, cnt);
+        refl[0] = c[0] * mat->kr; refl[1] = c[1] * mat->kr; refl[2] = c[2] * mat->kr;
+    }
+    if (mat->refractive && depth <= prm->max_depth && sinSqrPhit <= 1) { /* :391-396 */
+        ray_t r;
+        r.d = vadd(vmul(ray->d, n), vmul(refractNormal, n * cosI - cosT));
+        r.o = vsub(hitPt, vmul(refractNormal, bias));
+        float c[3];
+        trace(sc, prm, &r, depth, c, cnt);
+        refr[0] = c[0] * mat->kt; refr[1] = c[1] * mat->kt; refr[2] = c[2] * mat->kt;
+    }
+    cr += mat->color[0] * mat->ka; /* :399 */
+    cg += mat->color[1] * mat->ka;
+    cb += mat->color[2] * mat->ka;
+    if (mat->refractive) { /* :400-404 */
+        const float t = 1 - rCoef;
+        cr += refl[0] * rCoef + refr[0] * t;
+        cg += refl[1] * rCoef + refr[1] * t;
+        cb += refl[2] * rCoef + refr[2] * t;
+    } else {
+        cr += refl[0]; cg += refl[1]; cb += refl[2];
+    }
+    /* clamp(0,1) per level :406, common.h:47-52 */
+    cr = cr < 0 ? 0 : cr; cr = cr > 1 ? 1 : cr;
+    cg = cg < 0 ? 0 : cg; cg = cg > 1 ? 1 : cg;
+    cb = cb < 0 ? 0 : cb; cb = cb > 1 ? 1 : cb;
+    out[0] = cr; out[1] = cg; out[2] = cb;
+}
+
+/* ---- Camera::getCamRay, camera.h:57-66; deg2rad helper.cpp:13-15 ---- */
+static ray_t cam_ray(const rt_camera* c, float x, float y) {
+    const float px_ndc = x / (float)c->imWidth;
+    const float py_ndc = y / (float)c->imHeight;
+    const float rad = (float)((double)c->fov * M_PI / 180);
+    const double t = tan((double)rad * 0.5);
+    const float cam_x = (float)((double)((2 * px_ndc - 1) * c->aspectRatio) * t);
+    const float cam_y = (float)((double)(1 - 2 * py_ndc) * t);
+    v3 dir = vadd(vadd(vmul(vld(c->right), cam_x), vmul(vld(c->up), cam_y)), vld(c->at));
+    ray_t r;
+    r.o = vld(c->eye);
+    r.d = vnormalize(dir);
+    return r;
+}
+/* Camera::castRays, camera.h:72-79: ray k of pixel (x,y); k = 0 is the pixel corner */
+static ray_t cast_ray(const rt_camera* c, const rt_params* p, uint32_t x, uint32_t y, uint32_t k) {
+    if (k == 0) return cam_ray(c, (float)x, (float)y);
+    return cam_ray(c, (float)x + p->aa_xy[2 * (k - 1)], (float)y + p->aa_xy[2 * (k - 1) + 1]);
+}
+
+/* ================= exported (orc_*) ================= */
+
+/* Pixel loop of render(), raytracer.cpp:430-448, rows under OpenMP schedule(dynamic,10) as :431. */
+int orc_render(const rt_flat_scene* sc, const rt_camera* cam, const rt_params* prm, uint32_t x0, uint32_t y0,
+               uint32_t w, uint32_t h, uint8_t* bgr, rt_stats* stats, int threads) {
+    const uint32_t W = cam->imWidth;
+    const uint32_t spp = 1 + prm->n_aa;
+    counters_t total;
+    memset(&total, 0, sizeof total);
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#else
+    (void)threads;
+#endif
+#pragma omp parallel
+    {
+        counters_t cnt;
+        memset(&cnt, 0, sizeof cnt);
+#pragma omp for schedule(dynamic, 10)
+        for (uint32_t y = y0; y < y0 + h; ++y) {
+            uint8_t* p = bgr + 3 * ((size_t)y * W + x0);
+            for (uint32_t x = x0; x < x0 + w; ++x) {
+                float pr = 0, pg = 0, pb = 0;
+                const float inv = 1 / (float)(size_t)spp; /* color.h:27-30: Color / numRays */
+                for (uint32_t k = 0; k < spp; ++k) {
+                    const ray_t r = cast_ray(cam, prm, x, y, k);
+                    float c[3];
+                    trace(sc, prm, &r, 0, c, &cnt);
+                    pr += c[0] * inv; pg += c[1] * inv; pb += c[2] * inv;
+                }
+                *p++ = (uint8_t)(pb * 255); /* :446-448 BGR, truncation */
+                *p++ = (uint8_t)(pg * 255);
+                *p++ = (uint8_t)(pr * 255);
+            }
+        }
+#pragma omp critical
+        {
+            total.trace_calls += cnt.trace_calls;
+            total.shadow_rays += cnt.shadow_rays;
+            for (int i = 0; i < 16; ++i) total.level_rays[i] += cnt.level_rays[i];
+        }
+    }
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->trace_calls = total.trace_calls;
+        stats->shadow_rays = total.shadow_rays;
+        memcpy(stats->level_rays, total.level_rays, sizeof total.level_rays);
+        stats->passes = 1;
+    }
+    return 0;
+}
+
+int orc_trace(const rt_flat_scene* sc, const rt_params* prm, const float* rays, uint32_t n, float* rgb,
+              rt_stats* stats) {
+    counters_t total;
+    memset(&total, 0, sizeof total);
+#pragma omp parallel
+    {
+        counters_t cnt;
+        memset(&cnt, 0, sizeof cnt);
+#pragma omp for schedule(dynamic, 64)
+        for (uint32_t i = 0; i < n; ++i) {
+            ray_t r;
+            r.o = vld(rays + 6 * (size_t)i);
+            r.d = vld(rays + 6 * (size_t)i + 3);
+            trace(sc, prm, &r, 0, rgb + 3 * (size_t)i, &cnt);
+        }
+#pragma omp critical
+        {
+            total.trace_calls += cnt.trace_calls;
+            total.shadow_rays += cnt.shadow_rays;
+            for (int i = 0; i < 16; ++i) total.level_rays[i] += cnt.level_rays[i];
+        }
+    }
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->trace_calls = total.trace_calls;
+        stats->shadow_rays = total.shadow_rays;
+        memcpy(stats->level_rays, total.level_rays, sizeof total.level_rays);
+    }
+    return 0;
+}
+
+int orc_cast_rays(const rt_camera* cam, const rt_params* prm, const uint32_t* xy, uint32_t n, float* out) {
+    const uint32_t spp = 1 + prm->n_aa;
+    for (uint32_t i = 0; i < n; ++i)
+        for (uint32_t k = 0; k < spp; ++k) {
+            const ray_t r = cast_ray(cam, prm, xy[2 * i], xy[2 * i + 1], k);
+            float* o = out + ((size_t)i * spp + k) * 6;
+            o[0] = r.o.x; o[1] = r.o.y; o[2] = r.o.z; o[3] = r.d.x; o[4] = r.d.y; o[5] = r.d.z;
+        }
+    return 0;
+}
+
+/* Same contract as rt_intersect / ref_intersect. */
+int orc_intersect(const rt_flat_scene* sc, int object, const float* rays, uint32_t n, int32_t* hit_obj,
+                  float* dist, float* normal) {
+#pragma omp parallel for schedule(dynamic, 64)
+    for (uint32_t i = 0; i < n; ++i) {
+        ray_t r;
+        r.o = vld(rays + 6 * (size_t)i);
+        r.d = vld(rays + 6 * (size_t)i + 3);
+        float d = 0;
+        v3 nrm = V(0, 0, 0);
+        int hit = -1;
+        if (object >= 0) {
+            if (object_intersect(sc, (uint32_t)object, &r, &d, &nrm)) hit = object;
+        } else {
+            float best = FLT_MAX, tmp = 0;
+            v3 tn = V(0, 0, 0);
+            for (uint32_t k = 0; k < sc->n_objects; ++k)
+                if (object_intersect(sc, k, &r, &tmp, &tn) && tmp < best) { best = tmp; nrm = tn; hit = (int)k; }
+            d = best;
+        }
+        hit_obj[i] = hit;
+        dist[i] = d;
+        normal[3 * (size_t)i] = nrm.x; normal[3 * (size_t)i + 1] = nrm.y; normal[3 * (size_t)i + 2] = nrm.z;
+    }
+    return 0;
+}
+
+int orc_occluded(const rt_flat_scene* sc, const float* rays, const float* max_dist, uint32_t n, uint8_t* occ) {
+#pragma omp parallel for schedule(dynamic, 64)
+    for (uint32_t i = 0; i < n; ++i) {
+        ray_t r;
+        r.o = vld(rays + 6 * (size_t)i);
+        r.d = vld(rays + 6 * (size_t)i + 3);
+        float tmp = 0;
+        v3 tn = V(0, 0, 0);
+        int in = 0;
+        for (uint32_t k = 0; k < sc->n_objects; ++k) {
+            const int hit = object_intersect(sc, k, &r, &tmp, &tn);
+            if (hit && tmp < max_dist[i]) { in = 1; break; }
+        }
+        occ[i] = (uint8_t)in;
+    }
+    return 0;
+}

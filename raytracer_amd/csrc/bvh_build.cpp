@@ -1,0 +1,225 @@
+// bvh_build.cpp — host BVH builder (binned SAH) for the Model objects of a flat scene.
+//
+// Replaces the reference's O(#faces) loop in Model::intersect (reference src/primitives.cpp:376-382) with a
+// hierarchy the GPU can cull with; the reference has no acceleration structure (its bounding-sphere gate,
+// src/primitives.cpp:370, is kept separately and applied as is). The hierarchy only decides WHICH triangles get
+// tested; every accepted hit still comes from the reference's Moeller-Trumbore arithmetic, and ties are broken
+// by original face index, so closest hits equal the brute-force loop's (see DESIGN.md "BVH == brute force").
+//
+// Boxes are padded outward (relative 2e-5 of the coordinate magnitude + 1e-7) so that a hit the float
+// Moeller-Trumbore test accepts slightly outside the exact triangle is still inside its leaf box.
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "rt_device.h"
+
+namespace {
+
+struct Box {
+    float lo[3], hi[3];
+    void reset() { for (int a = 0; a < 3; ++a) { lo[a] = INFINITY; hi[a] = -INFINITY; } }
+    void grow(const float* p) { for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], p[a]); hi[a] = std::max(hi[a], p[a]); } }
+    void grow(const Box& b) { for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], b.lo[a]); hi[a] = std::max(hi[a], b.hi[a]); } }
+    float half_area() const {
+        const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+struct Builder {
+    const rt_flat_scene* sc;
+    std::vector<Box> tri_box;        // per original face
+    std::vector<float> centroid;     // 3 per face
+    std::vector<uint32_t> order;     // permutation of faces, leaf order at the end
+    BvhNode* nodes;
+    std::atomic<uint32_t> n_nodes{0};
+    std::atomic<uint32_t> max_depth{0};
+
+    static constexpr int NBINS = 16;
+
+    Box range_box(uint32_t b, uint32_t e) const {
+        Box bx; bx.reset();
+        for (uint32_t i = b; i < e; ++i) bx.grow(tri_box[order[i]]);
+        return bx;
+    }
+
+    static void pad(const Box& in, float* lo, float* hi) {
+        for (int a = 0; a < 3; ++a) {
+            const float m = std::max(std::fabs(in.lo[a]), std::fabs(in.hi[a]));
+            const float d = m * 2e-5f + 1e-7f;
+            lo[a] = in.lo[a] - d;
+            hi[a] = in.hi[a] + d;
+        }
+    }
+
+    // Returns the child reference for faces order[b..e) and their (unpadded) box in `bx`.
+    uint32_t build(uint32_t b, uint32_t e, uint32_t depth, Box& bx) {
+        const uint32_t n = e - b;
+        bx = range_box(b, e);
+        if (n <= RT_MAX_LEAF_TRIS) {
+            uint32_t d = max_depth.load();
+            while (depth > d && !max_depth.compare_exchange_weak(d, depth)) {}
+            return RT_LEAF_BIT | ((n - 1) << 27) | b;
+        }
+        // depth guard: once a balanced split is the only way to stay within RT_BVH_MAX_DEPTH, use it
+        uint32_t need = 0;
+        while ((uint64_t(RT_MAX_LEAF_TRIS) << need) < n) ++need;
+        uint32_t mid = 0;
+        if (depth + need + 1 < RT_BVH_MAX_DEPTH) mid = sah_split(b, e, bx);
+        if (mid <= b || mid >= e) mid = median_split(b, e, bx);
+
+        const uint32_t idx = n_nodes.fetch_add(1);
+        Box lb, rb;
+        uint32_t lc, rc;
+        if (n > 100000) {
+#pragma omp task shared(lc, lb) default(shared)
+            lc = build(b, mid, depth + 1, lb);
+#pragma omp task shared(rc, rb) default(shared)
+            rc = build(mid, e, depth + 1, rb);
+#pragma omp taskwait
+        } else {
+            lc = build(b, mid, depth + 1, lb);
+            rc = build(mid, e, depth + 1, rb);
+        }
+        BvhNode& nd = nodes[idx];
+        pad(lb, nd.lo0, nd.hi0);
+        pad(rb, nd.lo1, nd.hi1);
+        nd.child0 = lc;
+        nd.child1 = rc;
+        nd.pad0 = nd.pad1 = 0;
+        return idx;
+    }
+
+    uint32_t median_split(uint32_t b, uint32_t e, const Box& bx) {
+        int axis = 0;
+        float ext = -1;
+        for (int a = 0; a < 3; ++a) if (bx.hi[a] - bx.lo[a] > ext) { ext = bx.hi[a] - bx.lo[a]; axis = a; }
+        const uint32_t mid = b + (e - b) / 2;
+        std::nth_element(order.begin() + b, order.begin() + mid, order.begin() + e, [&](uint32_t x, uint32_t y) {
+            const float cx = centroid[3 * size_t(x) + axis], cy = centroid[3 * size_t(y) + axis];
+            return cx < cy || (cx == cy && x < y);
+        });
+        return mid;
+    }
+
+    uint32_t sah_split(uint32_t b, uint32_t e, const Box& /*bx*/) {
+        Box cb; cb.reset();
+        for (uint32_t i = b; i < e; ++i) cb.grow(&centroid[3 * size_t(order[i])]);
+        float best_cost = INFINITY;
+        int best_axis = -1, best_bin = -1;
+        for (int axis = 0; axis < 3; ++axis) {
+            const float lo = cb.lo[axis], ext = cb.hi[axis] - lo;
+            if (!(ext > 0)) continue;
+            const float scale = NBINS / ext;
+            Box bins[NBINS];
+            uint32_t cnt[NBINS] = {0};
+            for (auto& x : bins) x.reset();
+            for (uint32_t i = b; i < e; ++i) {
+                const uint32_t f = order[i];
+                int k = int((centroid[3 * size_t(f) + axis] - lo) * scale);
+                k = k < 0 ? 0 : (k >= NBINS ? NBINS - 1 : k);
+                bins[k].grow(tri_box[f]);
+                ++cnt[k];
+            }
+            float right_area[NBINS];
+            uint32_t right_cnt[NBINS];
+            Box acc; acc.reset();
+            uint32_t c = 0;
+            for (int k = NBINS - 1; k > 0; --k) {
+                if (cnt[k]) acc.grow(bins[k]);
+                c += cnt[k];
+                right_area[k] = c ? acc.half_area() : 0;
+                right_cnt[k] = c;
+            }
+            acc.reset();
+            c = 0;
+            for (int k = 0; k < NBINS - 1; ++k) {
+                if (cnt[k]) acc.grow(bins[k]);
+                c += cnt[k];
+                if (c == 0 || right_cnt[k + 1] == 0) continue;
+                const float cost = acc.half_area() * float(c) + right_area[k + 1] * float(right_cnt[k + 1]);
+                if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = k; }
+            }
+        }
+        if (best_axis < 0) return b;   // all centroids equal: caller falls back to the median split
+        const float lo = cb.lo[best_axis], scale = NBINS / (cb.hi[best_axis] - lo);
+        auto it = std::partition(order.begin() + b, order.begin() + e, [&](uint32_t f) {
+            int k = int((centroid[3 * size_t(f) + best_axis] - lo) * scale);
+            k = k < 0 ? 0 : (k >= NBINS ? NBINS - 1 : k);
+            return k <= best_bin;
+        });
+        return uint32_t(it - order.begin());
+    }
+};
+
+}  // namespace
+
+int bvh_build(const rt_flat_scene* sc, BvhBuildResult* out) {
+    std::memset(out, 0, sizeof *out);
+    const uint32_t nf = sc->n_faces;
+    Builder B;
+    B.sc = sc;
+    B.tri_box.resize(nf);
+    B.centroid.resize(size_t(nf) * 3);
+    B.order.resize(nf);
+#pragma omp parallel for schedule(static)
+    for (uint32_t f = 0; f < nf; ++f) {
+        Box bx; bx.reset();
+        bx.grow(sc->v0 + 3 * size_t(f));
+        bx.grow(sc->v1 + 3 * size_t(f));
+        bx.grow(sc->v2 + 3 * size_t(f));
+        B.tri_box[f] = bx;
+        for (int a = 0; a < 3; ++a) B.centroid[3 * size_t(f) + a] = 0.5f * (bx.lo[a] + bx.hi[a]);
+        B.order[f] = f;
+    }
+    // order[] must be a permutation within each model's own face range
+    for (uint32_t m = 0; m < sc->n_models; ++m) {
+        const rt_model& md = sc->models[m];
+        if (uint64_t(md.first_face) + md.num_faces > nf) return -1;
+    }
+    out->nodes = static_cast<BvhNode*>(std::malloc(sizeof(BvhNode) * std::max<size_t>(1, nf)));
+    out->model_root = static_cast<uint32_t*>(std::malloc(sizeof(uint32_t) * std::max<uint32_t>(1, sc->n_models)));
+    out->tris = static_cast<TriIsect*>(std::malloc(sizeof(TriIsect) * std::max<size_t>(1, nf)));
+    if (!out->nodes || !out->model_root || !out->tris) { bvh_free(out); return -2; }
+    B.nodes = out->nodes;
+    for (uint32_t m = 0; m < sc->n_models; ++m) {
+        const rt_model& md = sc->models[m];
+        if (md.num_faces == 0) { out->model_root[m] = RT_NO_CHILD; continue; }
+        Box bx;
+        uint32_t root = 0;
+#pragma omp parallel
+#pragma omp single
+        root = B.build(md.first_face, md.first_face + md.num_faces, 0, bx);
+        out->model_root[m] = root;
+    }
+    out->n_nodes = B.n_nodes.load();
+    out->max_depth = B.max_depth.load();
+    out->n_tris = nf;
+#pragma omp parallel for schedule(static)
+    for (uint32_t i = 0; i < nf; ++i) {
+        const uint32_t f = B.order[i];
+        TriIsect& t = out->tris[i];
+        const float* a = sc->v0 + 3 * size_t(f);
+        const float* b = sc->v1 + 3 * size_t(f);
+        const float* c = sc->v2 + 3 * size_t(f);
+        for (int k = 0; k < 3; ++k) {
+            t.v0[k] = a[k];
+            t.e1[k] = b[k] - a[k];   // v0v1, reference src/primitives.cpp:52
+            t.e2[k] = c[k] - a[k];   // v0v2, reference src/primitives.cpp:53
+        }
+        t.face = f;
+        t.pad1 = t.pad2 = 0;
+    }
+    return 0;
+}
+
+void bvh_free(BvhBuildResult* r) {
+    std::free(r->nodes);
+    std::free(r->tris);
+    std::free(r->model_root);
+    std::memset(r, 0, sizeof *r);
+}

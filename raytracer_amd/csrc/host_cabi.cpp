@@ -1,0 +1,115 @@
+// host_cabi.cpp — C entry points over the C++ host surface (include/raytracer_amd_host.h).
+// Compiled with -ffp-contract=off: the host data must match the reference's x86 build bit for bit.
+#include "raytracer_amd_host.h"
+
+#include "../host/raytracer.hpp"
+
+void rt_set_error(const char* fmt, ...);   // rt_api.cpp
+
+namespace {
+Vec3f v3(const float* p) { return Vec3f(p[0], p[1], p[2]); }
+void put(float* d, const Vec3f& v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; }
+}  // namespace
+
+struct rt_host_model {
+    std::unique_ptr<Model> m;
+};
+
+extern "C" {
+
+int rt_host_camera_make(const float* eye, const float* up, const float* at, float aspect, float fov,
+                        uint32_t W, uint32_t H, const float* rot, const float* move, rt_camera* out) {
+    if (!eye || !up || !at || !out) { rt_set_error("rt_host_camera_make: null argument"); return RT_ERR_INVALID; }
+    Camera cam(v3(eye), v3(up), v3(at), aspect, fov, W, H, Camera::noAntiAliasing());
+    if (rot) cam.rotate(rot[0], rot[1], rot[2]);
+    if (move) cam.move(v3(move));
+    *out = cam.flat();
+    return RT_OK;
+}
+
+int rt_host_plane_make(const float* normal, float dist, rt_plane* out) {
+    if (!normal || !out) { rt_set_error("rt_host_plane_make: null argument"); return RT_ERR_INVALID; }
+    const Plane p(v3(normal), dist, Material());
+    out->a = p.a; out->b = p.b; out->c = p.c; out->d = p.d;
+    return RT_OK;
+}
+
+int rt_host_mat3_rotation(float rx, float ry, float rz, float* out9) {
+    if (!out9) { rt_set_error("rt_host_mat3_rotation: null argument"); return RT_ERR_INVALID; }
+    const Mat3d m = Mat3d::rotation(rx, ry, rz);
+    for (int i = 0; i < 9; ++i) out9[i] = m[i];
+    return RT_OK;
+}
+
+int rt_host_bbvol(const float* v0, const float* v1, const float* v2, uint32_t n, float* bb) {
+    if (!v0 || !v1 || !v2 || !bb) { rt_set_error("rt_host_bbvol: null argument"); return RT_ERR_INVALID; }
+    std::vector<Triangle> faces;
+    faces.reserve(n);
+    const Vec3f z(0, 0, 0);
+    for (uint32_t f = 0; f < n; ++f)
+        faces.emplace_back(v3(v0 + 3 * size_t(f)), v3(v1 + 3 * size_t(f)), v3(v2 + 3 * size_t(f)), z, z, z);
+    const Model m(Material(), faces);
+    put(bb, m.bbvol.center);
+    bb[3] = m.bbvol.radius;
+    return RT_OK;
+}
+
+int rt_host_model_load_ply(const char* fname, rt_host_model** out) {
+    if (!fname || !out) { rt_set_error("rt_host_model_load_ply: null argument"); return RT_ERR_INVALID; }
+    try {
+        std::unique_ptr<Model> m(Model::load_ply(fname, Material(), true));
+        *out = new rt_host_model{std::move(m)};
+        return RT_OK;
+    } catch (const std::exception& e) {
+        rt_set_error("rt_host_model_load_ply: %s", e.what());
+        return RT_ERR_INVALID;
+    }
+}
+
+int rt_host_model_transform(rt_host_model* h, const float* rot, double scale, const float* tr) {
+    if (!h || !rot || !tr) { rt_set_error("rt_host_model_transform: null argument"); return RT_ERR_INVALID; }
+    *h->m *= Mat3d::rotation(v3(rot));
+    h->m->scale(Float(scale));
+    *h->m += v3(tr);
+    return RT_OK;
+}
+
+uint32_t rt_host_model_num_faces(const rt_host_model* h) { return h ? uint32_t(h->m->faces.size()) : 0; }
+
+int rt_host_model_get(const rt_host_model* h, float* v0, float* v1, float* v2, float* n0, float* n1, float* n2,
+                      float* bb) {
+    if (!h) { rt_set_error("rt_host_model_get: null model"); return RT_ERR_INVALID; }
+    size_t i = 0;
+    for (const auto& f : h->m->faces) {
+        if (v0) put(v0 + 3 * i, f.v0);
+        if (v1) put(v1 + 3 * i, f.v1);
+        if (v2) put(v2 + 3 * i, f.v2);
+        if (n0) put(n0 + 3 * i, f.n0);
+        if (n1) put(n1 + 3 * i, f.n1);
+        if (n2) put(n2 + 3 * i, f.n2);
+        ++i;
+    }
+    if (bb) { put(bb, h->m->bbvol.center); bb[3] = h->m->bbvol.radius; }
+    return RT_OK;
+}
+
+void rt_host_model_free(rt_host_model* h) { delete h; }
+
+int rt_host_known_answers(float* out) {
+    if (!out) { rt_set_error("rt_host_known_answers: null argument"); return RT_ERR_INVALID; }
+    Vec3f v1, v2(1, 2, 3);
+    v1 += v2;
+    put(out, v1);
+    put(out + 3, v1 * 2);
+    Color c1, c2(1, 2, 3);
+    c1 += c2;
+    const Color cc = c1 * c2, c2x = c1 * 2;
+    out[6] = cc.r; out[7] = cc.g; out[8] = cc.b;
+    out[9] = c2x.r; out[10] = c2x.g; out[11] = c2x.b;
+    const Vec3f cp = cross_product(Vec3f(1, 0, 0), Vec3f(0, 1, 0));
+    put(out + 12, cp);
+    out[15] = float(std::cos(double(cp.dotProduct(Vec3f(1, 0, 0)))));
+    return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,636 @@
+// rt_api.cpp — host side of the C-ABI (include/raytracer_amd.h): validation, BVH build + upload, the per-frame
+// launch schedule (passes -> levels -> fold -> resolve), statistics. No intersection or shading happens here.
+//
+// One rt_scene = one device. Its workspace (node pool, child-ray pool, counters) is owned by the scene and
+// reused by every call, so calls on the SAME rt_scene must not overlap; different scenes are independent.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "raytracer_amd.h"
+#include "rt_device.h"
+#include "rt_launch.h"
+
+// ---------------------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void rt_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) {                                                                    \
+            rt_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return RT_ERR_DEVICE;                                                                  \
+        }                                                                                          \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------------------
+// scene object
+// ---------------------------------------------------------------------------------------------------------
+struct PassCounters {                 // one per pass, zeroed by one memset per frame
+    uint32_t level[RT_MAX_LEVELS + 4];   // entries appended per level (index 0 unused)
+    uint32_t overflow;
+    uint32_t pad[3];
+    unsigned long long shadow;
+    unsigned long long work[4];
+};
+
+#define RT_MAX_PASSES 4096
+#define RT_PASS_SAMPLES (4u << 20)    // level-0 samples per pass
+#define RT_POOL_FACTOR 3u             // node pool = 3x the pass size (level 0 + 2x for all deeper levels)
+#define RT_MAX_TIMED 2048
+#define RT_LEVEL_GRID 4096u           // workgroups of a level >= 1 launch (grid-stride over the device-side count)
+
+struct rt_scene {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DScene d{};                        // device pointers
+    std::vector<void*> owned;          // everything to hipFree
+    uint32_t n_models = 0, n_faces = 0, n_nodes = 0, bvh_depth = 0;
+    uint64_t scene_bytes = 0;
+    bool has_bounce = false;           // some object's material is reflective or refractive
+    // workspace
+    uint32_t pool_cap = 0, ws_n0 = 0;
+    float4* node_a = nullptr;
+    uint4* node_b = nullptr;
+    float4* rays = nullptr;
+    PassCounters* d_counters = nullptr;
+    PassCounters* h_counters = nullptr;   // pinned
+    float* d_aa = nullptr;
+    uint8_t* d_frame = nullptr; size_t frame_bytes = 0;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    std::vector<hipEvent_t> ev_pool;
+    bool count_work = false;
+    rt_work last_work{};
+    int last_overflow = 0;
+};
+
+static int free_scene(rt_scene* s) {
+    if (!s) return RT_OK;
+    hipSetDevice(s->device);
+    for (void* p : s->owned) hipFree(p);
+    hipFree(s->node_a); hipFree(s->node_b); hipFree(s->rays); hipFree(s->d_counters); hipFree(s->d_aa); hipFree(s->d_frame);
+    if (s->h_counters) hipHostFree(s->h_counters);
+    if (s->ev_begin) hipEventDestroy(s->ev_begin);
+    if (s->ev_end) hipEventDestroy(s->ev_end);
+    for (hipEvent_t e : s->ev_pool) hipEventDestroy(e);
+    if (s->stream) hipStreamDestroy(s->stream);
+    delete s;
+    return RT_OK;
+}
+
+template <typename T>
+static int upload(rt_scene* s, const T* host, size_t n, const T** out) {
+    void* p = nullptr;
+    const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    HIP_TRY(hipMalloc(&p, bytes));
+    s->owned.push_back(p);
+    if (n) HIP_TRY(hipMemcpy(p, host, n * sizeof(T), hipMemcpyHostToDevice));
+    s->scene_bytes += bytes;
+    *out = static_cast<const T*>(p);
+    return RT_OK;
+}
+
+static int validate(const rt_flat_scene* sc) {
+    if (!sc) { rt_set_error("scene is NULL"); return RT_ERR_INVALID; }
+    if (sc->n_objects && !sc->objects) { rt_set_error("objects is NULL"); return RT_ERR_INVALID; }
+    if (sc->n_faces > RT_LEAF_START_MASK) { rt_set_error("n_faces %u above the maximum %u", sc->n_faces, RT_LEAF_START_MASK); return RT_ERR_LIMIT; }
+    if (sc->n_faces && (!sc->v0 || !sc->v1 || !sc->v2 || !sc->n0 || !sc->n1 || !sc->n2)) { rt_set_error("triangle arrays missing"); return RT_ERR_INVALID; }
+    for (uint32_t i = 0; i < sc->n_objects; ++i) {
+        const rt_object& o = sc->objects[i];
+        const uint32_t lim = o.type == RT_OBJ_SPHERE ? sc->n_spheres : o.type == RT_OBJ_PLANE ? sc->n_planes
+                             : o.type == RT_OBJ_MODEL ? sc->n_models : 0;
+        if (o.type < 0 || o.type > RT_OBJ_MODEL || o.index >= lim) { rt_set_error("object %u: bad type/index", i); return RT_ERR_INVALID; }
+        if (o.material >= sc->n_materials) { rt_set_error("object %u: material %u out of range", i, o.material); return RT_ERR_INVALID; }
+    }
+    for (uint32_t m = 0; m < sc->n_models; ++m)
+        if (uint64_t(sc->models[m].first_face) + sc->models[m].num_faces > sc->n_faces) { rt_set_error("model %u: face range out of bounds", m); return RT_ERR_INVALID; }
+    return RT_OK;
+}
+
+extern "C" int rt_scene_create(const rt_flat_scene* sc, int device, rt_scene** out) {
+    if (!out) { rt_set_error("out is NULL"); return RT_ERR_INVALID; }
+    *out = nullptr;
+    int rc = validate(sc);
+    if (rc != RT_OK) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { rt_set_error("no HIP device available"); return RT_ERR_NO_DEVICE; }
+    if (device < 0 || device >= ndev) { rt_set_error("device %d out of range (%d devices)", device, ndev); return RT_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(device));
+
+    BvhBuildResult bvh;
+    if (bvh_build(sc, &bvh) != 0) { rt_set_error("BVH build failed"); return RT_ERR_INVALID; }
+
+    rt_scene* s = new rt_scene();
+    s->device = device;
+    auto fail = [&](int code) { bvh_free(&bvh); free_scene(s); return code; };
+    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { rt_set_error("hipStreamCreate failed"); return fail(RT_ERR_DEVICE); }
+
+    std::vector<uint4> objs(sc->n_objects);
+    for (uint32_t i = 0; i < sc->n_objects; ++i) {
+        objs[i] = make_uint4(uint32_t(sc->objects[i].type), sc->objects[i].index, sc->objects[i].material, 0);
+        const rt_material& m = sc->materials[sc->objects[i].material];
+        if (m.reflective || m.refractive) s->has_bounce = true;
+    }
+    std::vector<float4> sph(sc->n_spheres), pl(sc->n_planes), li(size_t(sc->n_lights) * 2);
+    for (uint32_t i = 0; i < sc->n_spheres; ++i) sph[i] = make_float4(sc->spheres[i].center[0], sc->spheres[i].center[1], sc->spheres[i].center[2], sc->spheres[i].radius);
+    for (uint32_t i = 0; i < sc->n_planes; ++i) pl[i] = make_float4(sc->planes[i].a, sc->planes[i].b, sc->planes[i].c, sc->planes[i].d);
+    for (uint32_t i = 0; i < sc->n_lights; ++i) {
+        li[2 * i] = make_float4(sc->lights[i].pos[0], sc->lights[i].pos[1], sc->lights[i].pos[2], 0);
+        li[2 * i + 1] = make_float4(sc->lights[i].color[0], sc->lights[i].color[1], sc->lights[i].color[2], 0);
+    }
+    std::vector<DModel> models(sc->n_models);
+    for (uint32_t m = 0; m < sc->n_models; ++m) {
+        DModel& d = models[m];
+        d.root = bvh.model_root[m];
+        d.first_face = sc->models[m].first_face;
+        d.num_faces = sc->models[m].num_faces;
+        std::memcpy(d.bb_center, sc->models[m].bb_center, sizeof d.bb_center);
+        d.bb_radius = sc->models[m].bb_radius;
+        d.pad = 0;
+    }
+    std::vector<TriNormals> nrm(sc->n_faces);
+    for (uint32_t f = 0; f < sc->n_faces; ++f) {
+        TriNormals& t = nrm[f];
+        for (int k = 0; k < 3; ++k) { t.n0[k] = sc->n0[3 * size_t(f) + k]; t.n1[k] = sc->n1[3 * size_t(f) + k]; t.n2[k] = sc->n2[3 * size_t(f) + k]; }
+        t.pad0 = t.pad1 = t.pad2 = 0;
+    }
+    s->d.n_objects = sc->n_objects;
+    s->d.n_lights = sc->n_lights;
+    if ((rc = upload(s, objs.data(), objs.size(), &s->d.objects)) != RT_OK) return fail(rc);
+    if ((rc = upload(s, sph.data(), sph.size(), &s->d.spheres)) != RT_OK) return fail(rc);
+    if ((rc = upload(s, pl.data(), pl.size(), &s->d.planes)) != RT_OK) return fail(rc);
+    if ((rc = upload(s, models.data(), models.size(), &s->d.models)) != RT_OK) return fail(rc);
+    if ((rc = upload(s, sc->materials, size_t(sc->n_materials), &s->d.materials)) != RT_OK) return fail(rc);
+    if ((rc = upload(s, li.data(), li.size(), &s->d.lights)) != RT_OK) return fail(rc);
+    if ((rc = upload(s, bvh.nodes, size_t(bvh.n_nodes), &s->d.nodes)) != RT_OK) return fail(rc);
+    if ((rc = upload(s, bvh.tris, size_t(bvh.n_tris), &s->d.tris)) != RT_OK) return fail(rc);
+    if ((rc = upload(s, nrm.data(), nrm.size(), &s->d.normals)) != RT_OK) return fail(rc);
+    s->n_models = sc->n_models;
+    s->n_faces = sc->n_faces;
+    s->n_nodes = bvh.n_nodes;
+    s->bvh_depth = bvh.max_depth;
+    bvh_free(&bvh);
+
+    if (hipMalloc(reinterpret_cast<void**>(&s->d_counters), sizeof(PassCounters) * RT_MAX_PASSES) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&s->h_counters), sizeof(PassCounters) * RT_MAX_PASSES) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&s->d_aa), sizeof(float) * 2 * (RT_MAX_AA_POINTS + 1)) != hipSuccess ||
+        hipEventCreate(&s->ev_begin) != hipSuccess || hipEventCreate(&s->ev_end) != hipSuccess) {
+        rt_set_error("workspace allocation failed: %s", hipGetErrorString(hipGetLastError()));
+        free_scene(s);
+        return RT_ERR_DEVICE;
+    }
+    *out = s;
+    return RT_OK;
+}
+
+extern "C" void rt_scene_destroy(rt_scene* s) { free_scene(s); }
+
+extern "C" int rt_scene_bvh_info(const rt_scene* s, rt_bvh_info* out) {
+    if (!s || !out) { rt_set_error("null argument"); return RT_ERR_INVALID; }
+    out->n_nodes = s->n_nodes; out->n_faces = s->n_faces; out->max_depth = s->bvh_depth;
+    out->node_bytes = sizeof(BvhNode); out->tri_bytes = sizeof(TriIsect); out->reserved = 0;
+    out->device_bytes = s->scene_bytes;
+    return RT_OK;
+}
+
+extern "C" int rt_set_count_work(rt_scene* s, int enable) {
+    if (!s) { rt_set_error("null scene"); return RT_ERR_INVALID; }
+    s->count_work = enable != 0;
+    return RT_OK;
+}
+extern "C" int rt_get_work(const rt_scene* s, rt_work* out) {
+    if (!s || !out) { rt_set_error("null argument"); return RT_ERR_INVALID; }
+    *out = s->last_work;
+    return RT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// frame schedule
+// ---------------------------------------------------------------------------------------------------------
+static int ensure_workspace(rt_scene* s, uint32_t n0) {
+    if (n0 <= s->ws_n0) return RT_OK;
+    hipFree(s->node_a); hipFree(s->node_b); hipFree(s->rays);
+    s->node_a = nullptr; s->node_b = nullptr; s->rays = nullptr; s->ws_n0 = 0; s->pool_cap = 0;
+    const uint64_t cap = uint64_t(n0) * RT_POOL_FACTOR;
+    if (cap > 0xFFFFFFF0ull) { rt_set_error("pass too large"); return RT_ERR_LIMIT; }
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->node_a), cap * sizeof(float4)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->node_b), cap * sizeof(uint4)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->rays), (cap - n0) * 2 * sizeof(float4)));
+    s->ws_n0 = n0;
+    s->pool_cap = uint32_t(cap);
+    return RT_OK;
+}
+
+static DCamera to_dcamera(const rt_camera* c) {
+    DCamera d;
+    std::memcpy(d.eye, c->eye, sizeof d.eye); std::memcpy(d.up, c->up, sizeof d.up);
+    std::memcpy(d.right, c->right, sizeof d.right); std::memcpy(d.at, c->at, sizeof d.at);
+    d.aspect = c->aspectRatio; d.imWidth = c->imWidth; d.imHeight = c->imHeight; d.pad = 0;
+    // deg2rad (reference src/helper.cpp:13-15) returns Float; `* 0.5` and tan are double (src/camera.h:60)
+    const float rad = float(double(c->fov) * M_PI / 180);
+    d.tan_half = std::tan(double(rad) * 0.5);
+    return d;
+}
+
+static int check_params(const rt_camera* cam, const rt_params* p) {
+    if (!cam || !p) { rt_set_error("camera/params is NULL"); return RT_ERR_INVALID; }
+    if (p->max_depth < 0 || p->max_depth >= RT_MAX_LEVELS) { rt_set_error("max_depth %d outside [0,%d]", p->max_depth, RT_MAX_LEVELS - 1); return RT_ERR_LIMIT; }
+    if (p->n_aa > RT_MAX_AA_POINTS) { rt_set_error("n_aa %u above the maximum %d", p->n_aa, RT_MAX_AA_POINTS); return RT_ERR_LIMIT; }
+    if (p->n_aa && !p->aa_xy) { rt_set_error("aa_xy is NULL"); return RT_ERR_INVALID; }
+    if (cam->imWidth == 0 || cam->imHeight == 0) { rt_set_error("empty image"); return RT_ERR_INVALID; }
+    return RT_OK;
+}
+
+struct FrameJob {
+    rt_scene* s;
+    hipStream_t st;
+    LevelArgs base;          // everything that is constant over the frame
+    uint8_t* d_out;
+    bool timed;
+    uint32_t n_timed;
+    uint32_t n_pass_used;
+};
+
+// Enqueue the passes covering pixels [px0, px0+npx) of the frame's pixel order, pass_px pixels at a time.
+// Records which PassCounters slot each pass used in `slots` (px0, npx, slot).
+struct PassRec { uint64_t px0; uint32_t npx; uint32_t slot; };
+
+static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass_px, std::vector<PassRec>& recs) {
+    rt_scene* s = J.s;
+    const uint32_t spp = J.base.spp;
+    for (uint64_t done = 0; done < npx; done += pass_px) {
+        if (J.n_pass_used >= RT_MAX_PASSES) { rt_set_error("frame needs more than %d passes", RT_MAX_PASSES); return RT_ERR_LIMIT; }
+        const uint32_t cnt = uint32_t(std::min<uint64_t>(pass_px, npx - done));
+        const uint32_t slot = J.n_pass_used++;
+        PassCounters* pc = s->d_counters + slot;
+        LevelArgs A = J.base;
+        A.n0 = cnt * spp;
+        A.sample0 = (px0 + done) * spp;
+        A.counters = pc->level;
+        A.overflow = &pc->overflow;
+        A.shadow_count = &pc->shadow;
+        A.work = pc->work;
+        const int levels = s->has_bounce ? A.max_depth : 0;
+        for (int lv = 0; lv <= levels; ++lv) {
+            A.level = lv;
+            const uint32_t grid = lv == 0 ? (A.n0 + RT_BLOCK - 1) / RT_BLOCK : RT_LEVEL_GRID;
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (J.timed && J.n_timed < RT_MAX_TIMED) {
+                while (s->ev_pool.size() < size_t(2 * (J.n_timed + 1))) {
+                    hipEvent_t e;
+                    HIP_TRY(hipEventCreate(&e));
+                    s->ev_pool.push_back(e);
+                }
+                e0 = s->ev_pool[2 * J.n_timed]; e1 = s->ev_pool[2 * J.n_timed + 1];
+                ++J.n_timed;
+                HIP_TRY(hipEventRecord(e0, J.st));
+            }
+            launch_trace_level(lv == 0 ? 0 : 1, s->count_work, s->d, A, grid, J.st);
+            if (e1) HIP_TRY(hipEventRecord(e1, J.st));
+        }
+        for (int lv = levels - 1; lv >= 1; --lv) {
+            A.level = lv;
+            launch_fold(s->d, A, 1024, J.st);
+        }
+        A.level = 0;
+        launch_resolve(s->d, A, J.d_out, J.st);
+        HIP_TRY(hipGetLastError());
+        recs.push_back({px0 + done, cnt, slot});
+    }
+    return RT_OK;
+}
+
+static int render_frame(rt_scene* s, const rt_camera* cam, const rt_params* prm, const PixelMap& pm, uint8_t* d_out,
+                        hipStream_t st, rt_stats* stats, bool sync) {
+    HIP_TRY(hipSetDevice(s->device));
+    const uint32_t spp = 1 + prm->n_aa;
+    const uint64_t total_px = uint64_t(pm.n_owned) * pm.tile_w * pm.tile_h;
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    if (total_px == 0) return RT_OK;
+    uint32_t pass_px = uint32_t(std::min<uint64_t>(total_px, std::max<uint32_t>(64u, RT_PASS_SAMPLES / spp)));
+    pass_px = (pass_px + 63u) & ~63u;
+    int rc = ensure_workspace(s, pass_px * spp);
+    if (rc != RT_OK) return rc;
+
+    FrameJob J{};
+    J.s = s; J.st = st; J.d_out = d_out; J.timed = stats != nullptr;
+    LevelArgs& B = J.base;
+    std::memset(&B, 0, sizeof B);
+    B.max_depth = prm->max_depth;
+    B.spp = spp;
+    B.pool_cap = s->pool_cap;
+    B.rays = s->rays; B.node_a = s->node_a; B.node_b = s->node_b;
+    B.aa = s->d_aa;
+    std::memcpy(B.background, prm->background, sizeof B.background);
+    B.pm = pm;
+    B.cam = to_dcamera(cam);
+    if (prm->n_aa) HIP_TRY(hipMemcpyAsync(s->d_aa, prm->aa_xy, sizeof(float) * 2 * prm->n_aa, hipMemcpyHostToDevice, st));
+
+    const uint64_t n_pass = (total_px + pass_px - 1) / pass_px;
+    if (n_pass > RT_MAX_PASSES) { rt_set_error("frame needs %llu passes (max %d)", (unsigned long long)n_pass, RT_MAX_PASSES); return RT_ERR_LIMIT; }
+    HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(PassCounters) * std::min<uint64_t>(RT_MAX_PASSES, n_pass * 2 + 16), st));
+    if (stats) HIP_TRY(hipEventRecord(s->ev_begin, st));
+
+    std::vector<PassRec> recs;
+    rc = enqueue_passes(J, 0, total_px, pass_px, recs);
+    if (rc != RT_OK) return rc;
+    if (!sync) {
+        // asynchronous call: overflow (if any) is left in the counters; rt_scene_status() reports it after a sync
+        s->last_overflow = -1;
+        return RT_OK;
+    }
+
+    // Synchronous: read the counters back, re-run overflowed passes at half the size until they fit.
+    size_t checked = 0;
+    uint32_t retries = 0;
+    std::vector<PassRec> final_recs;
+    while (checked < recs.size()) {
+        const size_t upto = recs.size();
+        HIP_TRY(hipMemcpyAsync(s->h_counters, s->d_counters, sizeof(PassCounters) * J.n_pass_used, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (size_t i = checked; i < upto; ++i) {
+            const PassRec r = recs[i];
+            if (!s->h_counters[r.slot].overflow) { final_recs.push_back(r); continue; }
+            ++retries;
+            if (r.npx <= 64) { rt_set_error("bounce queue overflow on a 64-pixel pass"); return RT_ERR_OVERFLOW; }
+            uint32_t half = ((r.npx / 2) + 63u) & ~63u;
+            if (J.n_pass_used + 2 > RT_MAX_PASSES) { rt_set_error("out of pass slots while retrying"); return RT_ERR_OVERFLOW; }
+            HIP_TRY(hipMemsetAsync(s->d_counters + J.n_pass_used, 0, sizeof(PassCounters) * 2, st));
+            rc = enqueue_passes(J, r.px0, r.npx, half, recs);
+            if (rc != RT_OK) return rc;
+        }
+        checked = upto;
+    }
+    s->last_overflow = 0;
+    if (stats) {
+        HIP_TRY(hipEventRecord(s->ev_end, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        rt_work w{};
+        for (const PassRec& r : final_recs) {
+            const PassCounters& pc = s->h_counters[r.slot];
+            // level 0: every valid sample is one trace() call; deeper levels: appended entries
+            stats->shadow_rays += pc.shadow;
+            for (int lv = 1; lv < RT_MAX_LEVELS; ++lv) stats->level_rays[lv] += pc.level[lv];
+            w.nodes_visited += pc.work[0]; w.tris_tested += pc.work[1]; w.spheres_tested += pc.work[2]; w.planes_tested += pc.work[3];
+        }
+        s->last_work = w;
+        stats->passes = uint32_t(final_recs.size());
+        stats->retries = retries;
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, s->ev_begin, s->ev_end));
+        stats->kernel_ms = ms;
+        float tms = 0;
+        for (uint32_t i = 0; i < J.n_timed; ++i) {
+            float t = 0;
+            HIP_TRY(hipEventElapsedTime(&t, s->ev_pool[2 * i], s->ev_pool[2 * i + 1]));
+            tms += t;
+        }
+        stats->trace_kernel_ms = tms;
+        stats->trace_launches = J.n_timed;
+    }
+    return RT_OK;
+}
+
+// Level-0 trace() calls = valid pixels x spp (known on the host).
+static void finish_stats(rt_stats* stats, uint64_t valid_px, uint32_t spp) {
+    if (!stats) return;
+    stats->level_rays[0] = valid_px * spp;
+    stats->trace_calls = 0;
+    for (int lv = 0; lv < RT_MAX_LEVELS; ++lv) stats->trace_calls += stats->level_rays[lv];
+}
+
+static PixelMap rect_map(const rt_camera* cam, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h) {
+    PixelMap pm{};
+    pm.x0 = x0; pm.y0 = y0; pm.w = w; pm.h = h;
+    pm.tile_w = (w + 7u) & ~7u; pm.tile_h = (h + 7u) & ~7u;
+    pm.tiles_x = 1; pm.tiles_y = 1; pm.part = 0; pm.n_parts = 1; pm.n_owned = (w && h) ? 1 : 0;
+    pm.tiled_out = 0; pm.stride_px = cam->imWidth;
+    return pm;
+}
+
+static int check_rect(const rt_camera* cam, uint32_t x0, uint32_t y0, uint32_t w, uint32_t h) {
+    if (uint64_t(x0) + w > cam->imWidth || uint64_t(y0) + h > cam->imHeight) {
+        rt_set_error("rectangle (%u,%u %ux%u) outside the %ux%u image", x0, y0, w, h, cam->imWidth, cam->imHeight);
+        return RT_ERR_INVALID;
+    }
+    if (uint64_t(((w + 7u) & ~7u)) * ((h + 7u) & ~7u) > 0x7FFFFFFFull) { rt_set_error("rectangle too large"); return RT_ERR_LIMIT; }
+    return RT_OK;
+}
+
+extern "C" int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_params* prm, uint32_t x0, uint32_t y0,
+                                uint32_t w, uint32_t h, uint8_t* d_bgr, void* stream, rt_stats* stats) {
+    if (!s || !d_bgr) { rt_set_error("null argument"); return RT_ERR_INVALID; }
+    int rc = check_params(cam, prm);
+    if (rc != RT_OK) return rc;
+    if ((rc = check_rect(cam, x0, y0, w, h)) != RT_OK) return rc;
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : s->stream;
+    rc = render_frame(s, cam, prm, rect_map(cam, x0, y0, w, h), d_bgr, st, stats, stats != nullptr);
+    if (rc == RT_OK) finish_stats(stats, uint64_t(w) * h, 1 + prm->n_aa);
+    return rc;
+}
+
+extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_params* prm, uint32_t x0, uint32_t y0, uint32_t w,
+                         uint32_t h, uint8_t* bgr, rt_stats* stats) {
+    if (!s || !bgr) { rt_set_error("null argument"); return RT_ERR_INVALID; }
+    int rc = check_params(cam, prm);
+    if (rc != RT_OK) return rc;
+    if ((rc = check_rect(cam, x0, y0, w, h)) != RT_OK) return rc;
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    if (w == 0 || h == 0) return RT_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    const size_t need = size_t(cam->imWidth) * cam->imHeight * 3;
+    if (need > s->frame_bytes) {
+        hipFree(s->d_frame); s->d_frame = nullptr; s->frame_bytes = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_frame), need));
+        s->frame_bytes = need;
+    }
+    rt_stats local;
+    rc = render_frame(s, cam, prm, rect_map(cam, x0, y0, w, h), s->d_frame, s->stream, stats ? stats : &local, true);
+    if (rc != RT_OK) return rc;
+    finish_stats(stats, uint64_t(w) * h, 1 + prm->n_aa);
+    const size_t pitch = size_t(cam->imWidth) * 3, off = (size_t(y0) * cam->imWidth + x0) * 3;
+    HIP_TRY(hipMemcpy2DAsync(bgr + off, pitch, s->d_frame + off, pitch, size_t(w) * 3, h, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return RT_OK;
+}
+
+extern "C" uint32_t rt_tiles_owned(uint32_t W, uint32_t H, uint32_t tw, uint32_t th, uint32_t part, uint32_t n_parts) {
+    if (!tw || !th || !n_parts || part >= n_parts) return 0;
+    const uint64_t n = uint64_t((W + tw - 1) / tw) * ((H + th - 1) / th);
+    return n > part ? uint32_t((n - part + n_parts - 1) / n_parts) : 0;
+}
+
+extern "C" int rt_render_tiles_device(rt_scene* s, const rt_camera* cam, const rt_params* prm, uint32_t tw, uint32_t th,
+                                      uint32_t part, uint32_t n_parts, uint8_t* d_tiles, void* stream, rt_stats* stats) {
+    if (!s || !d_tiles) { rt_set_error("null argument"); return RT_ERR_INVALID; }
+    int rc = check_params(cam, prm);
+    if (rc != RT_OK) return rc;
+    if (!tw || !th || (tw & 7u) || (th & 7u)) { rt_set_error("tile size must be a positive multiple of 8"); return RT_ERR_INVALID; }
+    if (!n_parts || part >= n_parts) { rt_set_error("part %u / n_parts %u invalid", part, n_parts); return RT_ERR_INVALID; }
+    PixelMap pm{};
+    pm.x0 = 0; pm.y0 = 0; pm.w = cam->imWidth; pm.h = cam->imHeight;
+    pm.tile_w = tw; pm.tile_h = th;
+    pm.tiles_x = (cam->imWidth + tw - 1) / tw; pm.tiles_y = (cam->imHeight + th - 1) / th;
+    pm.part = part; pm.n_parts = n_parts;
+    pm.n_owned = rt_tiles_owned(cam->imWidth, cam->imHeight, tw, th, part, n_parts);
+    pm.tiled_out = 1; pm.stride_px = 0;
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : s->stream;
+    rc = render_frame(s, cam, prm, pm, d_tiles, st, stats, stats != nullptr);
+    if (rc == RT_OK && stats) {
+        // valid pixels of the owned tiles
+        uint64_t valid = 0;
+        for (uint32_t j = 0; j < pm.n_owned; ++j) {
+            const uint32_t T = part + j * n_parts, tx = T % pm.tiles_x, ty = T / pm.tiles_x;
+            const uint32_t vw = std::min(tw, cam->imWidth - tx * tw), vh = std::min(th, cam->imHeight - ty * th);
+            valid += uint64_t(vw) * vh;
+        }
+        finish_stats(stats, valid, 1 + prm->n_aa);
+    }
+    return rc;
+}
+
+extern "C" int rt_untile_device(int device, uint32_t W, uint32_t H, uint32_t tw, uint32_t th, uint32_t n_parts,
+                                const uint8_t* d_tiles, uint8_t* d_bgr, void* stream) {
+    if (!d_tiles || !d_bgr || !tw || !th || !n_parts || !W || !H) { rt_set_error("bad argument"); return RT_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(device));
+    UntileArgs U{};
+    U.W = W; U.H = H; U.tile_w = tw; U.tile_h = th;
+    U.tiles_x = (W + tw - 1) / tw;
+    U.n_tiles = U.tiles_x * ((H + th - 1) / th);
+    U.n_parts = n_parts;
+    launch_untile(U, d_tiles, d_bgr, static_cast<hipStream_t>(stream));
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// unit entry points (parity tests)
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+    int alloc(size_t bytes) { return hipMalloc(&p, std::max<size_t>(bytes, 16)) == hipSuccess ? 0 : -1; }
+    template <typename T> T* as() { return static_cast<T*>(p); }
+};
+}  // namespace
+
+extern "C" int rt_cast_rays(int device, const rt_camera* cam, const rt_params* prm, const uint32_t* xy, uint32_t n, float* out) {
+    int rc = check_params(cam, prm);
+    if (rc != RT_OK) return rc;
+    if (!xy || !out) { rt_set_error("null argument"); return RT_ERR_INVALID; }
+    if (n == 0) return RT_OK;
+    HIP_TRY(hipSetDevice(device));
+    const uint32_t spp = 1 + prm->n_aa;
+    DevBuf daa, dxy, dout;
+    if (daa.alloc(sizeof(float) * 2 * prm->n_aa) || dxy.alloc(sizeof(uint32_t) * 2 * n) || dout.alloc(sizeof(float) * 6 * size_t(n) * spp)) {
+        rt_set_error("hipMalloc failed"); return RT_ERR_DEVICE;
+    }
+    if (prm->n_aa) HIP_TRY(hipMemcpy(daa.p, prm->aa_xy, sizeof(float) * 2 * prm->n_aa, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dxy.p, xy, sizeof(uint32_t) * 2 * n, hipMemcpyHostToDevice));
+    launch_cast_rays(to_dcamera(cam), daa.as<float>(), spp, dxy.as<uint32_t>(), n, dout.as<float>(), nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, dout.p, sizeof(float) * 6 * size_t(n) * spp, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+extern "C" int rt_intersect(rt_scene* s, int object, const float* rays, uint32_t n, int32_t* hit, float* dist, float* nrm) {
+    if (!s || !rays || !hit || !dist || !nrm) { rt_set_error("null argument"); return RT_ERR_INVALID; }
+    if (object >= int(s->d.n_objects)) { rt_set_error("object %d out of range", object); return RT_ERR_INVALID; }
+    if (n == 0) return RT_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    DevBuf dr, dh, dd, dn;
+    if (dr.alloc(sizeof(float) * 6 * n) || dh.alloc(sizeof(int32_t) * n) || dd.alloc(sizeof(float) * n) || dn.alloc(sizeof(float) * 3 * n)) {
+        rt_set_error("hipMalloc failed"); return RT_ERR_DEVICE;
+    }
+    HIP_TRY(hipMemcpy(dr.p, rays, sizeof(float) * 6 * n, hipMemcpyHostToDevice));
+    launch_intersect(s->d, object, dr.as<float>(), n, dh.as<int32_t>(), dd.as<float>(), dn.as<float>(), nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(hit, dh.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(dist, dd.p, sizeof(float) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(nrm, dn.p, sizeof(float) * 3 * n, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+extern "C" int rt_occluded(rt_scene* s, const float* rays, const float* max_dist, uint32_t n, uint8_t* occ) {
+    if (!s || !rays || !max_dist || !occ) { rt_set_error("null argument"); return RT_ERR_INVALID; }
+    if (n == 0) return RT_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    DevBuf dr, dm, dout;
+    if (dr.alloc(sizeof(float) * 6 * n) || dm.alloc(sizeof(float) * n) || dout.alloc(n)) { rt_set_error("hipMalloc failed"); return RT_ERR_DEVICE; }
+    HIP_TRY(hipMemcpy(dr.p, rays, sizeof(float) * 6 * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dm.p, max_dist, sizeof(float) * n, hipMemcpyHostToDevice));
+    launch_occluded(s->d, dr.as<float>(), dm.as<float>(), n, dout.as<uint8_t>(), nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(occ, dout.p, n, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+extern "C" int rt_trace(rt_scene* s, const rt_params* prm, const float* rays, uint32_t n, float* rgb, rt_stats* stats) {
+    if (!s || !prm || !rays || !rgb) { rt_set_error("null argument"); return RT_ERR_INVALID; }
+    if (prm->max_depth < 0 || prm->max_depth >= RT_MAX_LEVELS) { rt_set_error("max_depth %d outside [0,%d]", prm->max_depth, RT_MAX_LEVELS - 1); return RT_ERR_LIMIT; }
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    if (n == 0) return RT_OK;
+    if (n > RT_PASS_SAMPLES) { rt_set_error("rt_trace takes at most %u rays per call", RT_PASS_SAMPLES); return RT_ERR_LIMIT; }
+    HIP_TRY(hipSetDevice(s->device));
+    int rc = ensure_workspace(s, (n + 63u) & ~63u);
+    if (rc != RT_OK) return rc;
+    DevBuf dr, dout;
+    if (dr.alloc(sizeof(float) * 6 * n) || dout.alloc(sizeof(float) * 3 * n)) { rt_set_error("hipMalloc failed"); return RT_ERR_DEVICE; }
+    HIP_TRY(hipMemcpy(dr.p, rays, sizeof(float) * 6 * n, hipMemcpyHostToDevice));
+    hipStream_t st = s->stream;
+    // the pool is sized for the workspace's pass; with n rays at level 0 the remaining entries serve deeper levels
+    HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(PassCounters), st));
+    LevelArgs A;
+    std::memset(&A, 0, sizeof A);
+    A.n0 = n; A.max_depth = prm->max_depth; A.spp = 1; A.pool_cap = s->pool_cap;
+    A.counters = s->d_counters->level; A.overflow = &s->d_counters->overflow; A.shadow_count = &s->d_counters->shadow;
+    A.work = s->d_counters->work;
+    A.node_a = s->node_a; A.node_b = s->node_b; A.user_rays = dr.as<float>();
+    // pool entry i >= n0 keeps its ray at rays[2*(i-n0)]; the ray array holds pool_cap - ws_n0 entries, so with
+    // n0 = n <= ws_n0 the usable pool shrinks accordingly
+    A.rays = s->rays;
+    A.pool_cap = s->pool_cap - (s->ws_n0 - n);
+    std::memcpy(A.background, prm->background, sizeof A.background);
+    const int levels = s->has_bounce ? A.max_depth : 0;
+    for (int lv = 0; lv <= levels; ++lv) {
+        A.level = lv;
+        launch_trace_level(lv == 0 ? 2 : 1, s->count_work, s->d, A, lv == 0 ? (n + RT_BLOCK - 1) / RT_BLOCK : RT_LEVEL_GRID, st);
+    }
+    for (int lv = levels - 1; lv >= 1; --lv) { A.level = lv; launch_fold(s->d, A, 1024, st); }
+    A.level = 0;
+    launch_resolve_rgb(s->d, A, dout.as<float>(), st);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(s->h_counters, s->d_counters, sizeof(PassCounters), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (s->h_counters[0].overflow) { rt_set_error("bounce queue overflow: pass fewer rays per rt_trace call"); return RT_ERR_OVERFLOW; }
+    HIP_TRY(hipMemcpy(rgb, dout.p, sizeof(float) * 3 * n, hipMemcpyDeviceToHost));
+    if (stats) {
+        const PassCounters& pc = s->h_counters[0];
+        stats->level_rays[0] = n;
+        for (int lv = 1; lv < RT_MAX_LEVELS; ++lv) stats->level_rays[lv] = pc.level[lv];
+        for (int lv = 0; lv < RT_MAX_LEVELS; ++lv) stats->trace_calls += stats->level_rays[lv];
+        stats->shadow_rays = pc.shadow;
+        stats->passes = 1;
+        s->last_work.nodes_visited = pc.work[0]; s->last_work.tris_tested = pc.work[1];
+        s->last_work.spheres_tested = pc.work[2]; s->last_work.planes_tested = pc.work[3];
+    }
+    return RT_OK;
+}
+
+extern "C" const char* rt_last_error(void) { return g_err; }
+extern "C" const char* rt_version(void) { return "raytracer_amd 0.1 (gfx950)"; }

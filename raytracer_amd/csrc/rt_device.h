@@ -1,0 +1,64 @@
+// rt_device.h — data layout shared by the host API (rt_api.cpp), the BVH builder (bvh_build.cpp) and the
+// HIP kernels (rt_kernels.hip). Plain structs only.
+#pragma once
+#include <stdint.h>
+
+#include "raytracer_amd.h"
+
+// ---- BVH node, 64 B = half a gfx950 128-B cache line, two per line, 16-B aligned quarters ----
+// Binary node holding the boxes of BOTH children, so one 64-B fetch decides both descents.
+// Child reference: bit 31 clear -> index of another BvhNode; bit 31 set -> leaf:
+//   bits 0..26 = first triangle (index into the leaf-ordered triangle array), bits 27..30 = count-1.
+struct BvhNode {
+    float lo0[3], hi0[3];
+    float lo1[3], hi1[3];
+    uint32_t child0, child1;
+    uint32_t pad0, pad1;
+};
+static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
+
+#define RT_LEAF_BIT 0x80000000u
+#define RT_LEAF_START_MASK 0x07FFFFFFu
+#define RT_MAX_LEAF_TRIS 4
+#define RT_BVH_MAX_DEPTH 30      // builder guarantee; traversal stack holds 32 entries
+#define RT_NO_CHILD 0xFFFFFFFFu
+
+// ---- leaf-ordered triangle record for intersection, 48 B: v0 + original face index, e1 = v1-v0, e2 = v2-v0 ----
+// e1/e2 are the float differences Triangle::intersect forms on every call (reference src/primitives.cpp:52-53);
+// forming them once on the host gives the same bits.
+struct TriIsect {
+    float v0[3]; uint32_t face;   // face = index into the ORIGINAL face arrays (tie-break + normals)
+    float e1[3]; float pad1;
+    float e2[3]; float pad2;
+};
+static_assert(sizeof(TriIsect) == 48, "TriIsect must be 48 bytes");
+
+// ---- per-face vertex normals in ORIGINAL face order, 48 B, fetched once per closest hit ----
+struct TriNormals {
+    float n0[3]; float pad0;
+    float n1[3]; float pad1;
+    float n2[3]; float pad2;
+};
+
+struct DModel {
+    uint32_t root;        // child reference of the model's BVH root (may itself be a leaf)
+    uint32_t first_face;
+    uint32_t num_faces;
+    float bb_center[3];
+    float bb_radius;      // < 0: no gate
+    uint32_t pad;
+};
+static_assert(sizeof(DModel) == 32, "DModel must be 32 bytes");
+
+// Host-side result of the BVH build for all models of a scene.
+struct BvhBuildResult {
+    BvhNode* nodes;        uint32_t n_nodes;
+    TriIsect* tris;        uint32_t n_tris;     // leaf order
+    uint32_t* model_root;                       // per model
+    uint32_t max_depth;
+};
+
+// Builds one BVH per model (binned SAH, <= RT_MAX_LEAF_TRIS per leaf, depth <= RT_BVH_MAX_DEPTH) into one shared
+// node array. Returns 0 on success. Caller frees with bvh_free.
+int bvh_build(const rt_flat_scene* scene, BvhBuildResult* out);
+void bvh_free(BvhBuildResult* r);

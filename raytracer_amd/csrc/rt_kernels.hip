@@ -1,0 +1,717 @@
+// rt_kernels.hip — hand-written HIP kernels (gfx950) of the render hot path.
+//
+// What runs here, and the reference code each part answers to:
+//   cam_ray / cast_ray        Camera::getCamRay / castRays            reference src/camera.h:57-79
+//   sphere_isect              Sphere::intersect + getNormal           reference src/primitives.cpp:173-203
+//   plane_isect               Plane::intersect                        reference src/primitives.cpp:11-25
+//   tri_isect                 Triangle::intersect (Moeller-Trumbore)  reference src/primitives.cpp:42-81,125
+//   model_closest / _any      Model::intersect                        reference src/primitives.cpp:364-384
+//   k_trace_level             trace(): closest hit, light loop, Fresnel, child rays   reference src/raytracer.cpp:279-396
+//   finish_color / k_fold     trace(): ambient + children + clamp     reference src/raytracer.cpp:399-406
+//   k_resolve                 render(): sample average + BGR8 quantisation  reference src/raytracer.cpp:436-448
+//
+// Structure (not the reference's): the recursion becomes level-synchronous. Level k's kernel takes every ray of
+// recursion depth k, finds its closest hit (objects in scene order; meshes through a BVH with an LDS stack), runs
+// the shadow tests and the Phong sums, writes one node record and appends the reflection / refraction child rays
+// to level k+1 with one atomic per wave (ballot + prefix count). Because the reference clamps the colour at EVERY
+// recursion level (raytracer.cpp:406) the tree is folded bottom-up afterwards, level by level, with exactly the
+// reference's expression per node; a throughput-product accumulator would be wrong.
+//
+// Arithmetic: IEEE binary32 with the reference's operation order, compiled with -ffp-contract=off (no FMA
+// contraction; the x86 reference build has none), correctly rounded f32 divide/sqrt (hipcc default), and double
+// exactly where the reference's overload resolution computes in double (sphere roots, pow, camera tan product).
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <stdint.h>
+
+#include "rt_device.h"
+#include "rt_launch.h"
+
+#define RT_EPS 0.000001f   // reference src/common.h:36
+
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 neg(V3 a) { return mk(-a.x, -a.y, -a.z); }
+// reference src/container.h:134-138
+__device__ __forceinline__ float dot(V3 a, V3 b) { return (a.x * b.x) + (a.y * b.y) + (a.z * b.z); }
+// reference src/container.h:151-158
+__device__ __forceinline__ V3 cross(V3 u, V3 v) { return mk(u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x); }
+// reference src/container.h:140-142: double sqrt of the float dot, narrowed == correctly rounded sqrtf
+__device__ __forceinline__ float length(V3 a) { return __fsqrt_rn(dot(a, a)); }
+// reference src/container.h:144-146
+__device__ __forceinline__ V3 normalize(V3 a) { return a * (1.0f / length(a)); }
+__device__ __forceinline__ bool isnan3(V3 a) { return isnan(a.x) || isnan(a.y) || isnan(a.z); }
+__device__ __forceinline__ float max_std(float a, float b) { return (a < b) ? b : a; }   // std::max
+__device__ __forceinline__ float min_std(float a, float b) { return (b < a) ? b : a; }   // std::min
+__device__ __forceinline__ V3 ld3(const float* p) { return mk(p[0], p[1], p[2]); }
+__device__ __forceinline__ V3 f4xyz(float4 v) { return mk(v.x, v.y, v.z); }
+
+struct Ray { V3 o, d; };
+__device__ __forceinline__ V3 ray_point(const Ray& r, float t) { return r.o + r.d * t; }   // container.h:255
+
+// ---------------------------------------------------------------------------------------------------------
+// Camera (reference src/camera.h:57-79). tan_half = tan(deg2rad(fov)*0.5) in double, formed once on the host.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ Ray cam_ray(const DCamera& c, float x, float y) {
+    const float px_ndc = x / (float)c.imWidth;
+    const float py_ndc = y / (float)c.imHeight;
+    const float cam_x = (float)((double)((2 * px_ndc - 1) * c.aspect) * c.tan_half);
+    const float cam_y = (float)((double)(1 - 2 * py_ndc) * c.tan_half);
+    const V3 dir = (mk(c.right[0], c.right[1], c.right[2]) * cam_x + mk(c.up[0], c.up[1], c.up[2]) * cam_y) +
+                   mk(c.at[0], c.at[1], c.at[2]);
+    Ray r;
+    r.o = mk(c.eye[0], c.eye[1], c.eye[2]);
+    r.d = normalize(dir);
+    return r;
+}
+__device__ __forceinline__ Ray cast_ray(const DCamera& c, const float* __restrict__ aa, uint32_t x, uint32_t y, uint32_t k) {
+    if (k == 0) return cam_ray(c, (float)x, (float)y);
+    return cam_ray(c, (float)x + aa[2 * (k - 1)], (float)y + aa[2 * (k - 1) + 1]);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Analytic primitives
+// ---------------------------------------------------------------------------------------------------------
+// reference src/primitives.cpp:173-203. `dist` is in/out: left untouched when neither branch applies.
+__device__ __forceinline__ bool sphere_isect(float4 s, const Ray& ray, float& dist, V3& normal) {
+    const V3 c = f4xyz(s);
+    const V3 temp = ray.o - c;
+    const float val1 = dot(temp, ray.d);
+    const float val2 = length(temp);
+    const float val3 = val1 * val1 - val2 * val2 + s.w * s.w;
+    if (val3 < 0) return false;
+    const double sq = sqrt((double)val3);           // the reference's sqrt(val3) is the double function
+    const float dist1 = (float)((double)(-val1) + sq);
+    const float dist2 = (float)((double)(-val1) - sq);
+    if (dist1 < 0 || dist2 < 0) dist = max_std(dist1, dist2);
+    else if (dist1 > 0 && dist2 > 0) dist = min_std(dist1, dist2);
+    const V3 n = ray_point(ray, dist) - c;
+    const float inv = (float)(1.0 / (double)s.w);  // container.h:72-75
+    normal = n * inv;
+    return dist > RT_EPS;
+}
+// The gate of Model::intersect only needs the boolean.
+__device__ __forceinline__ bool sphere_gate(float4 s, const Ray& ray) {
+    float d = 0;   // uninitialised in the reference (primitives.cpp:366); defined as 0
+    V3 n;
+    return sphere_isect(s, ray, d, n);
+}
+// reference src/primitives.cpp:11-25
+__device__ __forceinline__ bool plane_isect(float4 p, const Ray& ray, float& dist, V3& normal) {
+    normal = f4xyz(p);
+    const float vd = dot(normal, ray.d);
+    const float vo = dot(normal, ray.o) + p.w;
+    dist = -vo / vd;
+    return dist > RT_EPS;
+}
+
+// reference src/primitives.cpp:52-78,125 with e1 = v1-v0, e2 = v2-v0 formed on the host.
+__device__ __forceinline__ bool tri_isect(V3 v0, V3 e1, V3 e2, const Ray& ray, float& t, float& u, float& v) {
+    const V3 pVec = cross(ray.d, e2);
+    const float det = dot(pVec, e1);
+    if (fabsf(det) < RT_EPS) return false;
+    const float invDet = 1 / det;
+    const V3 tVec = ray.o - v0;
+    u = invDet * dot(pVec, tVec);
+    if (u < 0 || u > 1) return false;
+    const V3 qVec = cross(tVec, e1);
+    v = invDet * dot(qVec, ray.d);
+    if (v < 0 || u + v > 1) return false;
+    t = invDet * dot(qVec, e2);
+    return t > RT_EPS;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// BVH traversal. One lane = one ray; the stack of deferred children lives in LDS, one column per lane
+// (entry [level][lane]: conflict-free, lanes of a wave hit distinct banks). Depth <= RT_BVH_MAX_DEPTH by
+// construction (bvh_build.cpp), so 32 entries can never overflow.
+// ---------------------------------------------------------------------------------------------------------
+#define RT_STACK 32
+
+struct Work { uint32_t nodes, tris, spheres, planes; };
+
+__device__ __forceinline__ float slab(const float* lo, const float* hi, V3 o, V3 inv, float tmax, bool& hit) {
+    const float tx0 = (lo[0] - o.x) * inv.x, tx1 = (hi[0] - o.x) * inv.x;
+    const float ty0 = (lo[1] - o.y) * inv.y, ty1 = (hi[1] - o.y) * inv.y;
+    const float tz0 = (lo[2] - o.z) * inv.z, tz1 = (hi[2] - o.z) * inv.z;
+    // fminf/fmaxf return the non-NaN operand, so a 0*inf axis (origin on a slab plane, zero direction) never culls
+    float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), 0.0f));
+    float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tmax));
+    tf *= 1.0000005f;   // conservative far bound (robust slab test)
+    hit = tn <= tf;
+    return tn;
+}
+
+// ANY = false: closest hit over the model's faces, ties broken by the lower ORIGINAL face index, which is what
+// the reference's ascending strict-< scan keeps (primitives.cpp:376-382). Returns hit; t/u/v/face of the winner.
+// ANY = true : does some face have EPS < t < tmax (the shadow test `hit && tmpdist < ldist`, raytracer.cpp:320-321).
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ bool bvh_traverse(const DScene& S, uint32_t root, const Ray& ray, float tmax, float& best_t,
+                                             float& best_u, float& best_v, uint32_t& best_face, uint32_t* stack,
+                                             Work& wk) {
+    const V3 inv = mk(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+    float best = ANY ? tmax : FLT_MAX;
+    float tcull = best;       // FLT_MAX * (1+eps) would overflow; inf is fine too but keep it finite
+    bool found = false;
+    uint32_t face = 0xFFFFFFFFu;
+    float bu = 0, bv = 0;
+    int sp = 0;
+    uint32_t cur = root;
+    if (cur == RT_NO_CHILD) return false;
+    for (;;) {
+        if (!(cur & RT_LEAF_BIT)) {
+            const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
+            const float4 a = np[0], b = np[1], c = np[2];
+            const uint4 r = reinterpret_cast<const uint4*>(np)[3];
+            if (COUNT) wk.nodes++;
+            const float lo0[3] = {a.x, a.y, a.z}, hi0[3] = {a.w, b.x, b.y};
+            const float lo1[3] = {b.z, b.w, c.x}, hi1[3] = {c.y, c.z, c.w};
+            bool h0, h1;
+            const float t0 = slab(lo0, hi0, ray.o, inv, tcull, h0);
+            const float t1 = slab(lo1, hi1, ray.o, inv, tcull, h1);
+            if (h0 && h1) {
+                const bool first0 = t0 <= t1;
+                stack[sp * RT_BLOCK] = first0 ? r.y : r.x;
+                ++sp;
+                cur = first0 ? r.x : r.y;
+            } else if (h0) {
+                cur = r.x;
+            } else if (h1) {
+                cur = r.y;
+            } else {
+                if (sp == 0) break;
+                --sp;
+                cur = stack[sp * RT_BLOCK];
+            }
+        } else {
+            const uint32_t start = cur & RT_LEAF_START_MASK;
+            const uint32_t cnt = ((cur >> 27) & 15u) + 1u;
+            for (uint32_t i = 0; i < cnt; ++i) {
+                const float4* tp = reinterpret_cast<const float4*>(S.tris + (start + i));
+                const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+                if (COUNT) wk.tris++;
+                float t, u, v;
+                if (tri_isect(f4xyz(q0), f4xyz(q1), f4xyz(q2), ray, t, u, v)) {
+                    const uint32_t f = __float_as_uint(q0.w);
+                    if (ANY) {
+                        if (t < tmax) return true;
+                    } else if (t < best || (t == best && f < face)) {
+                        best = t; bu = u; bv = v; face = f; found = true;
+                        tcull = t * 1.000001f;
+                    }
+                }
+            }
+            if (sp == 0) break;
+            --sp;
+            cur = stack[sp * RT_BLOCK];
+        }
+    }
+    if (!ANY && found) { best_t = best; best_u = bu; best_v = bv; best_face = face; }
+    return found;
+}
+
+// Model::intersect (reference src/primitives.cpp:364-384): dist = FLT_MAX, bounding-sphere gate, closest face,
+// normal = (1-u-v)*n0 + u*n1 + v*n2 (primitives.cpp:80, not normalised).
+template <bool COUNT>
+__device__ __forceinline__ bool model_closest(const DScene& S, const DModel& m, const Ray& ray, float& dist, V3& normal,
+                                              uint32_t* stack, Work& wk) {
+    dist = FLT_MAX;
+    if (m.bb_radius >= 0) {
+        if (COUNT) wk.spheres++;
+        if (!sphere_gate(make_float4(m.bb_center[0], m.bb_center[1], m.bb_center[2], m.bb_radius), ray)) return false;
+    }
+    float t, u, v;
+    uint32_t face;
+    if (!bvh_traverse<false, COUNT>(S, m.root, ray, FLT_MAX, t, u, v, face, stack, wk)) return false;
+    const float4* np = reinterpret_cast<const float4*>(S.normals + face);
+    const V3 n0 = f4xyz(np[0]), n1 = f4xyz(np[1]), n2 = f4xyz(np[2]);
+    dist = t;
+    normal = (n0 * (1 - u - v) + n1 * u) + n2 * v;
+    return true;   // every accepted face already satisfied dist > EPS
+}
+template <bool COUNT>
+__device__ __forceinline__ bool model_any(const DScene& S, const DModel& m, const Ray& ray, float tmax, uint32_t* stack,
+                                          Work& wk) {
+    if (m.bb_radius >= 0) {
+        if (COUNT) wk.spheres++;
+        if (!sphere_gate(make_float4(m.bb_center[0], m.bb_center[1], m.bb_center[2], m.bb_radius), ray)) return false;
+    }
+    float t, u, v;
+    uint32_t face;
+    return bvh_traverse<true, COUNT>(S, m.root, ray, tmax, t, u, v, face, stack, wk);
+}
+
+// Closest-hit loop of trace() (reference src/raytracer.cpp:292-300): objects in scene order, strict <.
+// The object table is read with wave-uniform indices (scalar loads); only the per-lane tests diverge.
+template <bool COUNT>
+__device__ __forceinline__ int closest_hit(const DScene& S, const Ray& ray, float& dist, V3& hitNormal, float& tmpdist,
+                                           uint32_t* stack, Work& wk) {
+    dist = FLT_MAX;
+    int cur = -1;
+    V3 tmpnormal = mk(0, 0, 0);
+    for (uint32_t k = 0; k < S.n_objects; ++k) {
+        const uint4 ob = S.objects[k];
+        bool hit;
+        if (ob.x == RT_OBJ_SPHERE) {
+            if (COUNT) wk.spheres++;
+            hit = sphere_isect(S.spheres[ob.y], ray, tmpdist, tmpnormal);
+        } else if (ob.x == RT_OBJ_PLANE) {
+            if (COUNT) wk.planes++;
+            hit = plane_isect(S.planes[ob.y], ray, tmpdist, tmpnormal);
+        } else {
+            hit = model_closest<COUNT>(S, S.models[ob.y], ray, tmpdist, tmpnormal, stack, wk);
+        }
+        if (hit && tmpdist < dist) {
+            dist = tmpdist;
+            hitNormal = tmpnormal;
+            cur = (int)k;
+        }
+    }
+    return cur;
+}
+
+// Shadow loop of trace() (reference src/raytracer.cpp:319-325): any object with hit && tmpdist < ldist.
+template <bool COUNT>
+__device__ __forceinline__ bool occluded(const DScene& S, const Ray& ray, float ldist, float& tmpdist, uint32_t* stack,
+                                         Work& wk) {
+    V3 tmpnormal;
+    bool in = false;
+    for (uint32_t k = 0; k < S.n_objects; ++k) {
+        const uint4 ob = S.objects[k];
+        if (!in) {
+            if (ob.x == RT_OBJ_SPHERE) {
+                if (COUNT) wk.spheres++;
+                const bool hit = sphere_isect(S.spheres[ob.y], ray, tmpdist, tmpnormal);
+                in = hit && tmpdist < ldist;
+            } else if (ob.x == RT_OBJ_PLANE) {
+                if (COUNT) wk.planes++;
+                const bool hit = plane_isect(S.planes[ob.y], ray, tmpdist, tmpnormal);
+                in = hit && tmpdist < ldist;
+            } else {
+                in = model_any<COUNT>(S, S.models[ob.y], ray, ldist, stack, wk);
+                if (!in) tmpdist = FLT_MAX;   // Model::intersect leaves FLT_MAX in dist on a miss (primitives.cpp:368)
+            }
+        }
+    }
+    return in;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Node records and the per-level clamp
+// ---------------------------------------------------------------------------------------------------------
+#define NODE_FOLD 1u     // has at least one child ray: colour is finished by the fold pass
+#define NODE_VALID 2u
+
+// reference src/raytracer.cpp:399-406. refl/refr are the children's colours already scaled by kr / kt
+// (raytracer.cpp:387,395), zero when the child does not exist (raytracer.cpp:384,390).
+__device__ __forceinline__ V3 finish_color(V3 color, const rt_material& m, float rCoef, V3 refl, V3 refr) {
+    color = color + mk(m.color[0] * m.ka, m.color[1] * m.ka, m.color[2] * m.ka);
+    if (m.refractive) {
+        const float t = 1 - rCoef;
+        color = color + (refl * rCoef + refr * t);
+    } else {
+        color = color + refl;
+    }
+    color.x = color.x < 0 ? 0 : color.x; color.x = color.x > 1 ? 1 : color.x;
+    color.y = color.y < 0 ? 0 : color.y; color.y = color.y > 1 ? 1 : color.y;
+    color.z = color.z < 0 ? 0 : color.z; color.z = color.z > 1 ? 1 : color.z;
+    return color;
+}
+
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// Wave-aggregated append: one atomic per wave for all lanes with `want`; returns the lane's slot.
+__device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool want) {
+    const unsigned long long mask = __ballot(want);
+    if (mask == 0) return 0;
+    const uint32_t lane = lane_id();
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// Sample index -> pixel. Pixels are numbered so that 64 consecutive ones form an 8x8 block (bit-interleaved
+// inside the block): a wave's primary rays stay close together for the BVH.
+__device__ __forceinline__ bool map_pixel(const PixelMap& pm, uint64_t q, uint32_t& x, uint32_t& y, uint64_t& out_off, bool& in_buf) {
+    const uint32_t per_tile = pm.tile_w * pm.tile_h;
+    const uint32_t j = (uint32_t)(q / per_tile);        // ordinal of the owned tile
+    const uint32_t r = (uint32_t)(q % per_tile);
+    const uint32_t sub_x = pm.tile_w >> 3;               // 8x8 sub-blocks per tile row
+    const uint32_t sb = r >> 6, w = r & 63u;
+    const uint32_t mx = (w & 1u) | ((w >> 1) & 2u) | ((w >> 2) & 4u);
+    const uint32_t my = ((w >> 1) & 1u) | ((w >> 2) & 2u) | ((w >> 3) & 4u);
+    const uint32_t lx = (sb % sub_x) * 8u + mx, ly = (sb / sub_x) * 8u + my;
+    const uint32_t T = pm.part + j * pm.n_parts;         // global tile id, row-major
+    const uint32_t tx = T % pm.tiles_x, ty = T / pm.tiles_x;
+    x = pm.x0 + tx * pm.tile_w + lx;
+    y = pm.y0 + ty * pm.tile_h + ly;
+    const bool valid = j < pm.n_owned && ty < pm.tiles_y && x < pm.x0 + pm.w && y < pm.y0 + pm.h;
+    in_buf = j < pm.n_owned;
+    if (pm.tiled_out) out_off = (((uint64_t)j * pm.tile_h + ly) * pm.tile_w + lx) * 3u;
+    else out_off = ((uint64_t)y * pm.stride_px + x) * 3u;
+    return valid;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_trace_level: one recursion level of trace() for all rays of that level.
+//   SRC 0: level 0, rays generated from the camera     SRC 1: level >= 1, rays read from the pool
+//   SRC 2: level 0, rays supplied by the caller (rt_trace)
+// ---------------------------------------------------------------------------------------------------------
+template <int SRC, bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) void k_trace_level(DScene S, LevelArgs A) {
+    __shared__ uint32_t lds_stack[RT_STACK * RT_BLOCK];
+    uint32_t* stack = lds_stack + threadIdx.x;
+
+    // level range inside the pool: [begin, end)
+    uint32_t begin = 0, end = A.n0;
+    if (SRC == 1) {
+        uint64_t e = A.n0;
+        for (int i = 1; i < A.level; ++i) e += A.counters[i];
+        // 64-bit sums: after an overflow the counters hold the ATTEMPTED appends (flagged by the producing level)
+        const uint64_t b64 = e, e64 = e + A.counters[A.level];
+        begin = (uint32_t)(b64 < A.pool_cap ? b64 : A.pool_cap);
+        end = (uint32_t)(e64 < A.pool_cap ? e64 : A.pool_cap);
+    }
+    const uint32_t next_base = end;               // children of this level are appended behind it
+    uint32_t* next_count = A.counters + (A.level + 1);
+
+    Work wk = {0, 0, 0, 0};
+    uint32_t n_shadow = 0;
+
+    for (uint32_t i = begin + blockIdx.x * RT_BLOCK + threadIdx.x; i < ((end - begin + RT_BLOCK - 1) / RT_BLOCK) * RT_BLOCK + begin;
+         i += gridDim.x * RT_BLOCK) {
+        const bool active = i < end;
+        Ray ray;
+        ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 0);
+        bool valid = active;
+        if (active) {
+            if (SRC == 0) {
+                const uint64_t g = A.sample0 + (i - begin);
+                uint32_t x, y; uint64_t off; bool inb;
+                valid = map_pixel(A.pm, g / A.spp, x, y, off, inb);
+                if (valid) ray = cast_ray(A.cam, A.aa, x, y, (uint32_t)(g % A.spp));
+            } else if (SRC == 1) {
+                const float4 o = A.rays[2 * (size_t)(i - A.n0)], d = A.rays[2 * (size_t)(i - A.n0) + 1];
+                ray.o = f4xyz(o); ray.d = f4xyz(d);
+            } else {
+                const float* p = A.user_rays + 6 * (size_t)i;
+                ray.o = ld3(p); ray.d = ld3(p + 3);
+            }
+        }
+
+        float4 rec_a = make_float4(0, 0, 0, 0);
+        uint4 rec_b = make_uint4(RT_NO_CHILD, RT_NO_CHILD, 0, 0);
+        bool want_refl = false, want_refr = false;
+        Ray r_refl, r_refr;
+        r_refl.o = r_refl.d = r_refr.o = r_refr.d = mk(0, 0, 0);
+
+        if (valid) {
+            float dist, tmpdist = 0;    // tmpdist: uninitialised in the reference (raytracer.cpp:285); defined as 0
+            V3 hitNormal = mk(0, 0, 0);
+            const int cur = closest_hit<COUNT>(S, ray, dist, hitNormal, tmpdist, stack, wk);
+            if (cur < 0) {
+                rec_a = make_float4(A.background[0], A.background[1], A.background[2], 0);   // raytracer.cpp:302-304
+                rec_b.w = NODE_VALID;
+            } else {
+                const uint32_t mat_id = S.objects[cur].z;
+                const rt_material m = S.materials[mat_id];
+                const float bias = 0.0001f;                                                  // raytracer.cpp:286
+                const V3 hitPt = ray_point(ray, dist);
+                V3 color = mk(0, 0, 0);
+                bool red = false;
+                for (uint32_t li = 0; li < S.n_lights && !red; ++li) {                       // raytracer.cpp:311-345
+                    const float4 lp = S.lights[2 * li], lc = S.lights[2 * li + 1];
+                    V3 lv = f4xyz(lp) - hitPt;
+                    const float ldist = length(lv);
+                    lv = normalize(lv);
+                    Ray sr;
+                    sr.o = hitPt + hitNormal * bias;
+                    sr.d = lv;
+                    ++n_shadow;
+                    if (occluded<COUNT>(S, sr, ldist, tmpdist, stack, wk)) continue;
+                    if (isnan3(hitNormal)) { red = true; break; }                            // raytracer.cpp:330-332
+                    const float cosPhi = max_std(dot(hitNormal, lv), 0.0f);
+                    const float fd = cosPhi / (ldist * ldist);
+                    color = color + mk(((m.color[0] * lc.x) * m.kd) * fd, ((m.color[1] * lc.y) * m.kd) * fd,
+                                       ((m.color[2] * lc.z) * m.kd) * fd);
+                    const V3 reflectRay = (hitNormal * 2.0f) * dot(hitNormal, lv) - lv;
+                    const float cosAlpha = max_std(dot(reflectRay, lv), 0.0f);
+                    const float fs = (float)(pow((double)cosAlpha, (double)m.specRefExp) / (double)(ldist * ldist));
+                    color = color + mk((lc.x * m.ks) * fs, (lc.y * m.ks) * fs, (lc.z * m.ks) * fs);
+                }
+                if (red) {
+                    rec_a = make_float4(1, 0, 0, 0);
+                    rec_b.w = NODE_VALID;
+                } else {
+                    const int depth = A.level + 1;                                           // raytracer.cpp:347
+                    V3 refractNormal = hitNormal;
+                    float cosI = 0, cosT = 0, sinSqrPhit = 0, n1 = 0, n2 = 0, n = 0, rCoef = 0;
+                    if (m.refractive && depth <= A.max_depth) {                              // raytracer.cpp:357-381
+                        cosI = dot(ray.d, hitNormal);
+                        if (cosI < 0.0f) { n1 = 1.0f; n2 = m.refractiveIdx; cosI = -cosI; }
+                        else { n1 = m.refractiveIdx; n2 = 1.0f; refractNormal = neg(refractNormal); }
+                        n = n1 / n2;
+                        sinSqrPhit = n * n * (1 - cosI * cosI);
+                        if (sinSqrPhit <= 1) {
+                            cosT = __fsqrt_rn(1 - sinSqrPhit);
+                            const float Rorth = (n1 * cosI - n2 * cosT) / (n1 * cosI + n2 * cosT);
+                            const float Rpar = (n2 * cosI - n1 * cosT) / (n2 * cosI + n1 * cosT);
+                            rCoef = (Rorth * Rorth + Rpar * Rpar) / 2;
+                        } else {
+                            rCoef = 1;
+                        }
+                    }
+                    if (m.reflective && depth <= A.max_depth) {                              // raytracer.cpp:385-388
+                        want_refl = true;
+                        r_refl.d = (neg(hitNormal) * 2.0f) * dot(hitNormal, ray.d) + ray.d;
+                        r_refl.o = hitPt + hitNormal * bias;
+                    }
+                    if (m.refractive && depth <= A.max_depth && sinSqrPhit <= 1) {           // raytracer.cpp:391-396
+                        want_refr = true;
+                        r_refr.d = ray.d * n + refractNormal * (n * cosI - cosT);
+                        r_refr.o = hitPt - refractNormal * bias;
+                    }
+                    rec_b.z = mat_id;
+                    if (want_refl || want_refr) {
+                        rec_a = make_float4(color.x, color.y, color.z, rCoef);
+                        rec_b.w = NODE_VALID | NODE_FOLD;
+                    } else {
+                        const V3 c = finish_color(color, m, rCoef, mk(0, 0, 0), mk(0, 0, 0));
+                        rec_a = make_float4(c.x, c.y, c.z, rCoef);
+                        rec_b.w = NODE_VALID;
+                    }
+                }
+            }
+        }
+
+        // append child rays to the next level: one atomic per wave and child kind
+        const uint32_t s1 = wave_append(next_count, want_refl);
+        const uint32_t s2 = wave_append(next_count, want_refr);
+        if (want_refl) {
+            const uint64_t slot = (uint64_t)next_base + s1;
+            if (slot < A.pool_cap) {
+                A.rays[2 * (size_t)(slot - A.n0)] = make_float4(r_refl.o.x, r_refl.o.y, r_refl.o.z, 0);
+                A.rays[2 * (size_t)(slot - A.n0) + 1] = make_float4(r_refl.d.x, r_refl.d.y, r_refl.d.z, 0);
+                rec_b.x = (uint32_t)slot;
+            } else {
+                *A.overflow = 1;
+            }
+        }
+        if (want_refr) {
+            const uint64_t slot = (uint64_t)next_base + s2;
+            if (slot < A.pool_cap) {
+                A.rays[2 * (size_t)(slot - A.n0)] = make_float4(r_refr.o.x, r_refr.o.y, r_refr.o.z, 0);
+                A.rays[2 * (size_t)(slot - A.n0) + 1] = make_float4(r_refr.d.x, r_refr.d.y, r_refr.d.z, 0);
+                rec_b.y = (uint32_t)slot;
+            } else {
+                *A.overflow = 1;
+            }
+        }
+        if (active) {
+            A.node_a[i] = rec_a;
+            A.node_b[i] = rec_b;
+        }
+    }
+
+    // statistics: one atomic per wave
+    const uint32_t ns = wave_sum(n_shadow);
+    if (lane_id() == 0 && ns) atomicAdd(A.shadow_count, (unsigned long long)ns);
+    if (COUNT) {
+        const uint32_t a = wave_sum(wk.nodes), b = wave_sum(wk.tris), c = wave_sum(wk.spheres), d = wave_sum(wk.planes);
+        if (lane_id() == 0) {
+            atomicAdd(A.work + 0, (unsigned long long)a);
+            atomicAdd(A.work + 1, (unsigned long long)b);
+            atomicAdd(A.work + 2, (unsigned long long)c);
+            atomicAdd(A.work + 3, (unsigned long long)d);
+        }
+    }
+}
+
+// Colour of pool node i once its children (one level deeper) are final.
+__device__ __forceinline__ V3 node_color(const DScene& S, const float4* __restrict__ node_a, const uint4* __restrict__ node_b,
+                                         uint32_t i) {
+    const float4 a = node_a[i];
+    const uint4 b = node_b[i];
+    if (!(b.w & NODE_FOLD)) return mk(a.x, a.y, a.z);
+    const rt_material m = S.materials[b.z];
+    V3 refl = mk(0, 0, 0), refr = mk(0, 0, 0);
+    if (b.x != RT_NO_CHILD) { const float4 c = node_a[b.x]; refl = mk(c.x * m.kr, c.y * m.kr, c.z * m.kr); }   // kr * trace(...)
+    if (b.y != RT_NO_CHILD) { const float4 c = node_a[b.y]; refr = mk(c.x * m.kt, c.y * m.kt, c.z * m.kt); }   // kt * trace(...)
+    return finish_color(mk(a.x, a.y, a.z), m, a.w, refl, refr);
+}
+
+// Fold of one level (>= 1): finishes every node whose children were traced one level deeper.
+__global__ __launch_bounds__(256) void k_fold(DScene S, LevelArgs A) {
+    uint64_t e = A.n0;
+    for (int i = 1; i < A.level; ++i) e += A.counters[i];
+    const uint64_t e64 = e + A.counters[A.level];
+    const uint32_t begin = (uint32_t)(e < A.pool_cap ? e : A.pool_cap);
+    const uint32_t end = (uint32_t)(e64 < A.pool_cap ? e64 : A.pool_cap);
+    for (uint32_t i = begin + blockIdx.x * 256 + threadIdx.x; i < end; i += gridDim.x * 256) {
+        const uint4 b = A.node_b[i];
+        if (b.w & NODE_FOLD) {
+            const V3 c = node_color(S, A.node_a, A.node_b, i);
+            float4 a = A.node_a[i];
+            a.x = c.x; a.y = c.y; a.z = c.z;
+            A.node_a[i] = a;
+            A.node_b[i].w = b.w & ~NODE_FOLD;
+        }
+    }
+}
+
+// render(): px += trace(...) / numRays per sample, then (uchar)(c*255) as B,G,R (reference src/raytracer.cpp:436-448).
+// One thread per pixel of the pass; level-0 nodes of a pixel are consecutive.
+__global__ __launch_bounds__(256) void k_resolve(DScene S, LevelArgs A, uint8_t* __restrict__ out) {
+    const uint32_t npix = A.n0 / A.spp;
+    const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= npix) return;
+    uint32_t x, y; uint64_t off; bool inb;
+    const bool valid = map_pixel(A.pm, A.sample0 / A.spp + p, x, y, off, inb);
+    if (!valid) {
+        if (A.pm.tiled_out && inb) { out[off] = 0; out[off + 1] = 0; out[off + 2] = 0; }
+        return;
+    }
+    const float inv = 1 / (float)A.spp;        // color.h:27-30
+    V3 px = mk(0, 0, 0);
+    for (uint32_t s = 0; s < A.spp; ++s) {
+        const V3 c = node_color(S, A.node_a, A.node_b, p * A.spp + s);
+        px = px + c * inv;
+    }
+    out[off] = (uint8_t)(px.z * 255);
+    out[off + 1] = (uint8_t)(px.y * 255);
+    out[off + 2] = (uint8_t)(px.x * 255);
+}
+
+// rt_trace: float colours of the level-0 nodes.
+__global__ __launch_bounds__(256) void k_resolve_rgb(DScene S, LevelArgs A, float* __restrict__ rgb) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= A.n0) return;
+    const V3 c = node_color(S, A.node_a, A.node_b, i);
+    rgb[3 * (size_t)i] = c.x; rgb[3 * (size_t)i + 1] = c.y; rgb[3 * (size_t)i + 2] = c.z;
+}
+
+// Tile-major parts -> row-major BGR8 frame.
+__global__ __launch_bounds__(256) void k_untile(UntileArgs U, const uint8_t* __restrict__ tiles, uint8_t* __restrict__ out) {
+    const uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= (uint64_t)U.W * U.H) return;
+    const uint32_t x = (uint32_t)(p % U.W), y = (uint32_t)(p / U.W);
+    const uint32_t tx = x / U.tile_w, ty = y / U.tile_h;
+    const uint32_t T = ty * U.tiles_x + tx;
+    const uint32_t part = T % U.n_parts, j = T / U.n_parts;
+    // tiles of parts 0..part-1 come first: part q owns ceil((n_tiles - q) / n_parts) tiles
+    uint64_t before = 0;
+    for (uint32_t q = 0; q < part; ++q) before += (U.n_tiles - q + U.n_parts - 1) / U.n_parts;
+    const uint64_t src = (((before + j) * U.tile_h + (y % U.tile_h)) * U.tile_w + (x % U.tile_w)) * 3u;
+    const uint64_t dst = p * 3u;
+    out[dst] = tiles[src]; out[dst + 1] = tiles[src + 1]; out[dst + 2] = tiles[src + 2];
+}
+
+// ---- unit kernels for the parity tests (same device functions) ----
+__global__ __launch_bounds__(RT_BLOCK) void k_cast_rays(DCamera cam, const float* __restrict__ aa, uint32_t spp,
+                                                        const uint32_t* __restrict__ xy, uint32_t n, float* __restrict__ out) {
+    const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i >= n * spp) return;
+    const uint32_t p = i / spp, k = i % spp;
+    const Ray r = cast_ray(cam, aa, xy[2 * p], xy[2 * p + 1], k);
+    float* o = out + 6 * (size_t)i;
+    o[0] = r.o.x; o[1] = r.o.y; o[2] = r.o.z; o[3] = r.d.x; o[4] = r.d.y; o[5] = r.d.z;
+}
+
+__global__ __launch_bounds__(RT_BLOCK) void k_intersect(DScene S, int object, const float* __restrict__ rays, uint32_t n,
+                                                        int32_t* __restrict__ hit_obj, float* __restrict__ dist_out,
+                                                        float* __restrict__ normal_out) {
+    __shared__ uint32_t lds_stack[RT_STACK * RT_BLOCK];
+    uint32_t* stack = lds_stack + threadIdx.x;
+    const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    Ray ray;
+    ray.o = ld3(rays + 6 * (size_t)i); ray.d = ld3(rays + 6 * (size_t)i + 3);
+    Work wk = {0, 0, 0, 0};
+    float d = 0;
+    V3 nrm = mk(0, 0, 0);
+    int hit = -1;
+    if (object >= 0) {
+        const uint4 ob = S.objects[object];
+        bool h;
+        if (ob.x == RT_OBJ_SPHERE) h = sphere_isect(S.spheres[ob.y], ray, d, nrm);
+        else if (ob.x == RT_OBJ_PLANE) h = plane_isect(S.planes[ob.y], ray, d, nrm);
+        else h = model_closest<false>(S, S.models[ob.y], ray, d, nrm, stack, wk);
+        if (h) hit = object;
+    } else {
+        float tmp = 0;
+        hit = closest_hit<false>(S, ray, d, nrm, tmp, stack, wk);
+    }
+    hit_obj[i] = hit;
+    dist_out[i] = d;
+    normal_out[3 * (size_t)i] = nrm.x; normal_out[3 * (size_t)i + 1] = nrm.y; normal_out[3 * (size_t)i + 2] = nrm.z;
+}
+
+__global__ __launch_bounds__(RT_BLOCK) void k_occluded(DScene S, const float* __restrict__ rays, const float* __restrict__ max_dist,
+                                                       uint32_t n, uint8_t* __restrict__ occ) {
+    __shared__ uint32_t lds_stack[RT_STACK * RT_BLOCK];
+    uint32_t* stack = lds_stack + threadIdx.x;
+    const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    Ray ray;
+    ray.o = ld3(rays + 6 * (size_t)i); ray.d = ld3(rays + 6 * (size_t)i + 3);
+    Work wk = {0, 0, 0, 0};
+    float tmp = 0;
+    occ[i] = occluded<false>(S, ray, max_dist[i], tmp, stack, wk) ? 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Launchers (called from rt_api.cpp, which is plain C++)
+// ---------------------------------------------------------------------------------------------------------
+extern "C++" {
+
+void launch_trace_level(int src, bool count, const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st) {
+    dim3 g(grid), b(RT_BLOCK);
+    if (src == 0) {
+        if (count) hipLaunchKernelGGL((k_trace_level<0, true>), g, b, 0, st, S, A);
+        else hipLaunchKernelGGL((k_trace_level<0, false>), g, b, 0, st, S, A);
+    } else if (src == 1) {
+        if (count) hipLaunchKernelGGL((k_trace_level<1, true>), g, b, 0, st, S, A);
+        else hipLaunchKernelGGL((k_trace_level<1, false>), g, b, 0, st, S, A);
+    } else {
+        if (count) hipLaunchKernelGGL((k_trace_level<2, true>), g, b, 0, st, S, A);
+        else hipLaunchKernelGGL((k_trace_level<2, false>), g, b, 0, st, S, A);
+    }
+}
+void launch_fold(const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st) {
+    hipLaunchKernelGGL(k_fold, dim3(grid), dim3(256), 0, st, S, A);
+}
+void launch_resolve(const DScene& S, const LevelArgs& A, uint8_t* out, hipStream_t st) {
+    const uint32_t npix = A.n0 / A.spp;
+    hipLaunchKernelGGL(k_resolve, dim3((npix + 255) / 256), dim3(256), 0, st, S, A, out);
+}
+void launch_resolve_rgb(const DScene& S, const LevelArgs& A, float* rgb, hipStream_t st) {
+    hipLaunchKernelGGL(k_resolve_rgb, dim3((A.n0 + 255) / 256), dim3(256), 0, st, S, A, rgb);
+}
+void launch_untile(const UntileArgs& U, const uint8_t* tiles, uint8_t* out, hipStream_t st) {
+    const uint64_t n = (uint64_t)U.W * U.H;
+    hipLaunchKernelGGL(k_untile, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, U, tiles, out);
+}
+void launch_cast_rays(const DCamera& cam, const float* aa, uint32_t spp, const uint32_t* xy, uint32_t n, float* out,
+                      hipStream_t st) {
+    const uint32_t total = n * spp;
+    hipLaunchKernelGGL(k_cast_rays, dim3((total + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, st, cam, aa, spp, xy, n, out);
+}
+void launch_intersect(const DScene& S, int object, const float* rays, uint32_t n, int32_t* hit, float* dist, float* nrm,
+                      hipStream_t st) {
+    hipLaunchKernelGGL(k_intersect, dim3((n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, st, S, object, rays, n, hit, dist, nrm);
+}
+void launch_occluded(const DScene& S, const float* rays, const float* max_dist, uint32_t n, uint8_t* occ, hipStream_t st) {
+    hipLaunchKernelGGL(k_occluded, dim3((n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, st, S, rays, max_dist, n, occ);
+}
+
+}  // extern "C++"

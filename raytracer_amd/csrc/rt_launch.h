@@ -1,0 +1,83 @@
+// rt_launch.h — kernel argument blocks and launcher prototypes shared by rt_kernels.hip and rt_api.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_device.h"
+
+#define RT_BLOCK 64          // one wave per workgroup: waves retire independently, no barrier is ever needed
+#define RT_MAX_LEVELS 16     // recursion levels 0..max_depth, max_depth <= 15
+
+// Scene in HBM (SoA). All pointers are device pointers owned by rt_scene.
+struct DScene {
+    const uint4* objects;        // (type, index, material, 0), scene order
+    uint32_t n_objects;
+    uint32_t n_lights;
+    const float4* spheres;       // cx cy cz r
+    const float4* planes;        // a b c d
+    const DModel* models;
+    const rt_material* materials;
+    const float4* lights;        // 2 per light: pos, color
+    const BvhNode* nodes;
+    const TriIsect* tris;        // leaf order
+    const TriNormals* normals;   // original face order
+};
+
+struct DCamera {
+    float eye[3], up[3], right[3], at[3];
+    float aspect;
+    uint32_t imWidth, imHeight;
+    uint32_t pad;
+    double tan_half;             // tan(deg2rad(fov) * 0.5) evaluated in double on the host (camera.h:60-61)
+};
+
+// Which pixels a pass covers and where their bytes go. Pixel ordinal q -> owned tile j = q / (tile_w*tile_h),
+// global tile T = part + j*n_parts (row-major over tiles_x x tiles_y), 8x8 bit-interleaved blocks inside a tile.
+struct PixelMap {
+    uint32_t x0, y0, w, h;       // rectangle the tiles are laid over
+    uint32_t tile_w, tile_h;     // multiples of 8
+    uint32_t tiles_x, tiles_y;
+    uint32_t part, n_parts;
+    uint32_t n_owned;            // tiles this part owns
+    uint32_t tiled_out;          // 1: tile-major output buffer, 0: row-major full image
+    uint32_t stride_px;          // row-major: pixels per image row
+    uint32_t pad;
+};
+
+struct LevelArgs {
+    uint32_t n0;                 // level-0 samples of this pass (multiple of spp)
+    int32_t level;
+    int32_t max_depth;
+    uint32_t spp;
+    uint64_t sample0;            // first sample of the pass in the frame's sample order
+    uint32_t pool_cap;           // node pool entries (all levels)
+    uint32_t pad;
+    uint32_t* counters;          // [RT_MAX_LEVELS+1] entries appended per level (index 0 unused)
+    uint32_t* overflow;          // set to 1 if a child did not fit
+    unsigned long long* shadow_count;
+    unsigned long long* work;    // [4] nodes, tris, spheres, planes (COUNT builds only)
+    float4* rays;                // 2 per pool entry >= n0: origin, direction
+    float4* node_a;              // per pool entry: r g b rCoef
+    uint4* node_b;               // per pool entry: refl child, refr child, material, flags
+    const float* aa;             // anti-aliasing pattern (device)
+    const float* user_rays;      // SRC 2
+    float background[3];
+    float pad2;
+    PixelMap pm;
+    DCamera cam;
+};
+
+struct UntileArgs {
+    uint32_t W, H, tile_w, tile_h, tiles_x, n_tiles, n_parts, pad;
+};
+
+void launch_trace_level(int src, bool count, const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st);
+void launch_fold(const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st);
+void launch_resolve(const DScene& S, const LevelArgs& A, uint8_t* out, hipStream_t st);
+void launch_resolve_rgb(const DScene& S, const LevelArgs& A, float* rgb, hipStream_t st);
+void launch_untile(const UntileArgs& U, const uint8_t* tiles, uint8_t* out, hipStream_t st);
+void launch_cast_rays(const DCamera& cam, const float* aa, uint32_t spp, const uint32_t* xy, uint32_t n, float* out,
+                      hipStream_t st);
+void launch_intersect(const DScene& S, int object, const float* rays, uint32_t n, int32_t* hit, float* dist, float* nrm,
+                      hipStream_t st);
+void launch_occluded(const DScene& S, const float* rays, const float* max_dist, uint32_t n, uint8_t* occ, hipStream_t st);
