@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py - Mrays/s and ms/frame of the render hot path on N MI355X (one process per GPU).
+
+A "step" is one full frame of the workload (default: the reference's scene.yaml "bunny scene" at 1920x1080 with
+its own reflective materials, depth 10, 1 ray per pixel; the mesh is the 69,620-face procedural stand-in for
+bun_zipper.ply, which does not ship with the reference). The scene is resident in HBM before the timed region;
+the frame stays in HBM (device framebuffer).
+
+N = 1: rt_render_device renders the whole frame.
+N > 1: strong scaling of the same frame. 32x32-pixel tiles are dealt round-robin to the ranks (scene replicated),
+       each rank renders its tiles with rt_render_tiles_device, the tile buffers are gathered to rank 0 with
+       torch.distributed (backend nccl = RCCL over xGMI) and rank 0 scatters them into the row-major frame.
+
+Rays = trace() invocations + shadow rays, counted on the device.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
+VALU_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: FP32 vector peak
+
+
+def algorithmic_work(work, rays, closest_rays, n_lights):
+    """bytes/ray = 64 N_node + 48 N_tri + 16 N_sphere + 16 N_plane + 48;
+    flops/ray = 48 N_node + 47 N_tri + 35 N_sphere + 13 N_plane + S (S = 17 + 60 per light for closest-hit rays)."""
+    b = 64 * work.nodes_visited + 48 * work.tris_tested + 16 * work.spheres_tested + 16 * work.planes_tested + 48 * rays
+    f = (48 * work.nodes_visited + 47 * work.tris_tested + 35 * work.spheres_tested + 13 * work.planes_tested
+         + closest_rays * (17 + 60 * n_lights))
+    return b, f
+
+
+def cpu_baseline(fs, cam, params, dev, np):
+    """The reference's own objects (oracle/_ref, kind 'reference') or the C restatement ('port') on a bounded sample:
+    8 full-height strips, 4 pixels wide, evenly spread over the frame (rows under OpenMP schedule(dynamic,10) as the
+    reference's render())."""
+    from oracle import oracle as O
+    kind = "reference" if O.have_ref() else "port"
+    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("OMP_NUM_THREADS", "16")), 16)
+    backend = O.Reference(fs) if kind == "reference" else O.Oracle(fs)
+    W, H = cam.imWidth, cam.imHeight
+    strips = [(int(W * (k + 0.5) / 8), 0, 4, H) for k in range(8)]
+    rays = 0
+    secs = 0.0
+    same = True
+    for rect in strips:
+        g, st = dev.render(cam, params, rect=rect)
+        rays += st.trace_calls + st.shadow_rays
+        t = time.time()
+        c, _ = backend.render(cam, params, rect=rect, threads=cores)
+        secs += time.time() - t
+        d = np.abs(g.astype(np.int16) - c.astype(np.int16)).max(axis=2)
+        same = same and float((d <= 1).mean()) >= 0.999
+    return {"value": rays / secs / 1e6, "unit": "Mrays/s", "cores": cores, "kind": kind,
+            "sample": f"8 strips of 4x{H} px of the same frame ({rays} rays, {secs:.1f} s CPU wall)",
+            "gpu_matches_cpu_on_sample": bool(same)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="bunny_1080p")
+    ap.add_argument("--tile", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal only: every rank uses GPU 0 (needs --backend gloo)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from raytracer_amd import cabi, workloads as wl
+    from raytracer_amd.cabi import rt_stats
+    from raytracer_amd.scene import DeviceScene
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    if args.single_device:
+        local = 0
+    torch.cuda.set_device(local)
+    if world > 1:
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(args.backend)
+
+    fs, cam, params = wl.make_workload(args.workload)
+    t0 = time.time()
+    dev = DeviceScene(fs, device=local)
+    build_s = time.time() - t0
+    lib = dev.lib
+    W, H = cam.imWidth, cam.imHeight
+    stream = torch.cuda.current_stream().cuda_stream
+    frame = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+
+    # ray census of one frame (untimed), with the traversal work counters on
+    st = rt_stats()
+    work = None
+    if rank == 0:
+        dev.set_count_work(True)
+        dev.render_device(cam, params, frame.data_ptr(), stream=stream, stats=st)
+        work = dev.get_work()
+        dev.set_count_work(False)
+        ref_frame = frame.clone()
+    rays_per_frame = st.trace_calls + st.shadow_rays
+
+    tw = th = args.tile
+    if world > 1:
+        owned = lib.rt_tiles_owned(W, H, tw, th, rank, world)
+        slot = lib.rt_tiles_owned(W, H, tw, th, 0, world)       # part 0 owns the most tiles
+        mine = torch.zeros((slot * tw * th * 3,), dtype=torch.uint8, device="cuda")
+        gathered = [torch.zeros_like(mine) for _ in range(world)] if rank == 0 else None
+        allt = torch.zeros((world * slot * tw * th * 3,), dtype=torch.uint8, device="cuda") if rank == 0 else None
+
+    def step():
+        if world == 1:
+            dev.render_device(cam, params, frame.data_ptr(), stream=stream)
+        else:
+            dev.render_tiles_device(cam, params, (tw, th), rank, world, mine.data_ptr(), stream=stream)
+            dist.gather(mine, gathered, dst=0)
+            if rank == 0:
+                torch.cat(gathered, out=allt)
+                cabi.check(lib, lib.rt_untile_device(local, W, H, tw, th, world, slot, C.c_void_p(allt.data_ptr()),
+                                                     C.c_void_p(frame.data_ptr()), C.c_void_p(stream)))
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t
+    if world > 1:
+        e = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(e, op=dist.ReduceOp.MAX)
+        elapsed = float(e.item())
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        out = {
+            "metric": "Mrays/s", "value": rays_per_frame * args.steps / elapsed / 1e6, "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "ms_per_frame": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "width": W, "height": H, "spp": params.spp,
+                       "max_depth": params.c.max_depth, "triangles": fs.num_faces, "objects": len(fs.objects),
+                       "lights": len(fs.lights), "rays_per_frame": rays_per_frame,
+                       "trace_calls": st.trace_calls, "shadow_rays": st.shadow_rays,
+                       "parallelism": "1 GPU" if world == 1 else f"{world} GPUs: {tw}x{th} tiles round-robin, RCCL gather",
+                       "mesh": "procedural geodesic blob (no .ply ships with the reference)",
+                       "scene_build_s": round(build_s, 3)},
+        }
+        identical = bool(torch.equal(frame, ref_frame))
+        out["frame_identical_to_1gpu"] = identical
+        if world == 1:
+            # dominant kernel: k_trace_level. HIP events around every launch of it, on the launch stream.
+            reps = 10
+            tk_ms, launches, frame_ms = 0.0, 0, 0.0
+            for _ in range(reps):
+                s2 = rt_stats()
+                dev.render_device(cam, params, frame.data_ptr(), stream=stream, stats=s2)
+                tk_ms += s2.trace_kernel_ms
+                launches += s2.trace_launches
+                frame_ms += s2.kernel_ms
+            avg_launch_ms = tk_ms / launches
+            launches_per_frame = launches / reps
+            b, f = algorithmic_work(work, rays_per_frame, st.trace_calls, len(fs.lights))
+            bytes_per_launch = b / launches_per_frame
+            gbs = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9
+            tfl = (f / launches_per_frame) / (avg_launch_ms * 1e-3) / 1e12
+            out["roofline"] = {
+                "bound": "hbm", "kernel": "k_trace_level", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                "avg_launch_ms": avg_launch_ms, "launches_per_frame": launches_per_frame,
+                "algorithmic_bytes_per_launch": bytes_per_launch,
+                "trace_kernel_share_of_frame": tk_ms / frame_ms if frame_ms else None,
+                "valu": {"achieved": tfl, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / VALU_PEAK_TFLOPS},
+                "work_per_frame": {"bvh_nodes": work.nodes_visited, "tri_tests": work.tris_tested,
+                                   "sphere_tests": work.spheres_tested, "plane_tests": work.planes_tested},
+            }
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(fs, cam, params, dev, np)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -169,11 +169,13 @@ int rt_render_tiles_device(rt_scene* scene, const rt_camera* cam, const rt_param
 uint32_t rt_tiles_owned(uint32_t imWidth, uint32_t imHeight, uint32_t tile_w, uint32_t tile_h,
                         uint32_t part, uint32_t n_parts);
 
-/* Scatter gathered tile-major buffers (parts concatenated in part order, each rt_tiles_owned() tiles)
- * back into the reference's row-major BGR8 frame. d_tiles_all and d_bgr_out are device pointers.
+/* Scatter gathered tile-major buffers back into the reference's row-major BGR8 frame. Part q's tiles start at
+ * tile slot q*part_stride_tiles of d_tiles_all (part_stride_tiles >= every part's rt_tiles_owned(); pass 0 for parts
+ * packed back to back). d_tiles_all and d_bgr_out are device pointers.
  * Replaces: the shared `img` all render() workers write into (reference src/raytracer.cpp:434). */
 int rt_untile_device(int device, uint32_t imWidth, uint32_t imHeight, uint32_t tile_w, uint32_t tile_h,
-                     uint32_t n_parts, const uint8_t* d_tiles_all, uint8_t* d_bgr_out, void* stream);
+                     uint32_t n_parts, uint32_t part_stride_tiles, const uint8_t* d_tiles_all, uint8_t* d_bgr_out,
+                     void* stream);
 
 /* Unit entry points used by the parity tests (each runs the same device functions the renderer uses). */
 

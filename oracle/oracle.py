@@ -1,0 +1,183 @@
+"""TEST INFRASTRUCTURE ONLY. ctypes loaders for the parity oracle (oracle/librt_oracle.so, the plain-C
+restatement) and, where it has been built, the real reference objects (oracle/_ref/libref.so).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from raytracer_amd import cabi
+from raytracer_amd.cabi import FP, fptr, rt_camera, rt_flat_scene, rt_params, rt_plane, rt_stats, u8ptr
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(HERE, "librt_oracle.so")
+REF_SO = os.path.join(HERE, "_ref", "libref.so")
+
+
+def build(force=False):
+    """Compile the C restatement (and, when /root/reference is present, the reference harness)."""
+    if force or not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(
+            os.path.join(HERE, "rt_oracle.c")):
+        subprocess.check_call(["make", "-C", HERE, "librt_oracle.so"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", HERE, "ref"], stdout=subprocess.DEVNULL)
+
+
+_orc = None
+_ref = None
+
+
+def orc():
+    global _orc
+    if _orc is None:
+        if not os.path.exists(ORACLE_SO):
+            build()
+        lib = C.CDLL(ORACLE_SO)
+        u32 = C.c_uint32
+        lib.orc_render.argtypes = [C.POINTER(rt_flat_scene), C.POINTER(rt_camera), C.POINTER(rt_params), u32, u32,
+                                   u32, u32, C.POINTER(C.c_uint8), C.POINTER(rt_stats), C.c_int]
+        lib.orc_trace.argtypes = [C.POINTER(rt_flat_scene), C.POINTER(rt_params), FP, u32, FP, C.POINTER(rt_stats)]
+        lib.orc_cast_rays.argtypes = [C.POINTER(rt_camera), C.POINTER(rt_params), C.POINTER(u32), u32, FP]
+        lib.orc_intersect.argtypes = [C.POINTER(rt_flat_scene), C.c_int, FP, u32, C.POINTER(C.c_int32), FP, FP]
+        lib.orc_occluded.argtypes = [C.POINTER(rt_flat_scene), FP, FP, u32, C.POINTER(C.c_uint8)]
+        _orc = lib
+    return _orc
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+def ref():
+    global _ref
+    if _ref is None:
+        lib = C.CDLL(REF_SO)
+        u32, vp = C.c_uint32, C.c_void_p
+        lib.ref_scene_create.argtypes = [C.POINTER(rt_flat_scene)]
+        lib.ref_scene_create.restype = vp
+        lib.ref_scene_destroy.argtypes = [vp]
+        lib.ref_render.argtypes = [vp, C.POINTER(rt_camera), C.POINTER(rt_params), u32, u32, u32, u32,
+                                   C.POINTER(C.c_uint8), C.c_int]
+        lib.ref_trace.argtypes = [vp, C.POINTER(rt_params), FP, u32, FP]
+        lib.ref_cast_rays.argtypes = [C.POINTER(rt_camera), C.POINTER(rt_params), C.POINTER(u32), u32, FP]
+        lib.ref_intersect.argtypes = [vp, C.c_int, FP, u32, C.POINTER(C.c_int32), FP, FP]
+        lib.ref_occluded.argtypes = [vp, FP, FP, u32, C.POINTER(C.c_uint8)]
+        lib.ref_model_load.argtypes = [C.c_char_p, FP, C.c_double, FP, C.c_int]
+        lib.ref_model_load.restype = vp
+        lib.ref_model_num_faces.argtypes = [vp]
+        lib.ref_model_num_faces.restype = u32
+        lib.ref_model_get.argtypes = [vp, FP, FP, FP, FP, FP, FP, FP]
+        lib.ref_model_free.argtypes = [vp]
+        lib.ref_mat3_rotation.argtypes = [C.c_float, C.c_float, C.c_float, FP]
+        lib.ref_camera_make.argtypes = [FP, FP, FP, C.c_float, C.c_float, u32, u32, FP, FP, C.POINTER(rt_camera)]
+        lib.ref_plane_make.argtypes = [FP, C.c_float, C.POINTER(rt_plane)]
+        lib.ref_bbvol.argtypes = [FP, FP, FP, u32, FP]
+        lib.ref_known_answers.argtypes = [FP]
+        _ref = lib
+    return _ref
+
+
+class _Backend:
+    """Same calls on either library. kind = 'orc' (C restatement) or 'ref' (reference objects)."""
+
+    def __init__(self, kind, flat):
+        self.kind = kind
+        self.flat = flat
+        self.fs = flat.c_struct() if flat is not None else None
+        self.h = None
+        if kind == "ref" and flat is not None:
+            self.h = ref().ref_scene_create(C.byref(self.fs))
+
+    def close(self):
+        if self.h:
+            ref().ref_scene_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render(self, cam, params, rect=None, threads=0, out=None):
+        W, H = cam.imWidth, cam.imHeight
+        if out is None:
+            out = np.zeros((H, W, 3), np.uint8)
+        x0, y0, w, h = rect if rect is not None else (0, 0, W, H)
+        st = rt_stats()
+        if self.kind == "orc":
+            orc().orc_render(C.byref(self.fs), C.byref(cam), C.byref(params.c), x0, y0, w, h, u8ptr(out),
+                             C.byref(st), threads)
+        else:
+            ref().ref_render(self.h, C.byref(cam), C.byref(params.c), x0, y0, w, h, u8ptr(out), threads)
+        return out, st
+
+    def trace(self, params, rays):
+        rays = cabi.as_f32(rays, (-1, 6))
+        rgb = np.zeros((rays.shape[0], 3), np.float32)
+        st = rt_stats()
+        if self.kind == "orc":
+            orc().orc_trace(C.byref(self.fs), C.byref(params.c), fptr(rays), rays.shape[0], fptr(rgb), C.byref(st))
+        else:
+            ref().ref_trace(self.h, C.byref(params.c), fptr(rays), rays.shape[0], fptr(rgb))
+        return rgb, st
+
+    def intersect(self, rays, obj=-1):
+        rays = cabi.as_f32(rays, (-1, 6))
+        n = rays.shape[0]
+        hit = np.full(n, -2, np.int32)
+        dist = np.zeros(n, np.float32)
+        nrm = np.zeros((n, 3), np.float32)
+        hp = hit.ctypes.data_as(C.POINTER(C.c_int32))
+        if self.kind == "orc":
+            orc().orc_intersect(C.byref(self.fs), obj, fptr(rays), n, hp, fptr(dist), fptr(nrm))
+        else:
+            ref().ref_intersect(self.h, obj, fptr(rays), n, hp, fptr(dist), fptr(nrm))
+        return hit, dist, nrm
+
+    def occluded(self, rays, max_dist):
+        rays = cabi.as_f32(rays, (-1, 6))
+        md = cabi.as_f32(max_dist, (-1,))
+        occ = np.zeros(rays.shape[0], np.uint8)
+        if self.kind == "orc":
+            orc().orc_occluded(C.byref(self.fs), fptr(rays), fptr(md), rays.shape[0], u8ptr(occ))
+        else:
+            ref().ref_occluded(self.h, fptr(rays), fptr(md), rays.shape[0], u8ptr(occ))
+        return occ
+
+
+def Oracle(flat):
+    return _Backend("orc", flat)
+
+
+def Reference(flat):
+    return _Backend("ref", flat)
+
+
+def cast_rays(kind, cam, params, xy):
+    xy = np.ascontiguousarray(np.asarray(xy, dtype=np.uint32).reshape(-1, 2))
+    out = np.zeros((xy.shape[0], params.spp, 6), np.float32)
+    p = xy.ctypes.data_as(C.POINTER(C.c_uint32))
+    if kind == "orc":
+        orc().orc_cast_rays(C.byref(cam), C.byref(params.c), p, xy.shape[0], fptr(out))
+    else:
+        ref().ref_cast_rays(C.byref(cam), C.byref(params.c), p, xy.shape[0], fptr(out))
+    return out
+
+
+def ref_load_ply(path, rotation=(0, 0, 0), scale=1.0, translation=(0, 0, 0), transform=True):
+    """Model::load_ply + transform chain by the reference itself -> 6 x (F,3) arrays + bbvol."""
+    lib = ref()
+    rot = np.asarray(rotation, np.float32)
+    tr = np.asarray(translation, np.float32)
+    h = lib.ref_model_load(str(path).encode(), fptr(rot), float(scale), fptr(tr), int(transform))
+    if not h:
+        raise RuntimeError("reference load_ply failed")
+    n = lib.ref_model_num_faces(h)
+    arrs = [np.empty((n, 3), np.float32) for _ in range(6)]
+    bb = np.empty(4, np.float32)
+    lib.ref_model_get(h, *[fptr(a) for a in arrs], fptr(bb))
+    lib.ref_model_free(h)
+    return arrs, bb

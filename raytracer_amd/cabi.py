@@ -100,6 +100,12 @@ EXPORTS = [
     "rt_scene_bvh_info", "rt_set_count_work", "rt_get_work", "rt_last_error", "rt_version",
 ]
 
+HOST_EXPORTS = [
+    "rt_host_camera_make", "rt_host_plane_make", "rt_host_mat3_rotation", "rt_host_bbvol", "rt_host_model_load_ply",
+    "rt_host_model_transform", "rt_host_model_num_faces", "rt_host_model_get", "rt_host_model_free",
+    "rt_host_known_answers",
+]
+
 _lib = None
 
 
@@ -127,7 +133,7 @@ def load(path=None):
                                            u32, vp, vp, C.POINTER(rt_stats)]
     lib.rt_tiles_owned.argtypes = [u32] * 6
     lib.rt_tiles_owned.restype = u32
-    lib.rt_untile_device.argtypes = [C.c_int, u32, u32, u32, u32, u32, vp, vp, vp]
+    lib.rt_untile_device.argtypes = [C.c_int, u32, u32, u32, u32, u32, u32, vp, vp, vp]
     lib.rt_cast_rays.argtypes = [C.c_int, C.POINTER(rt_camera), C.POINTER(rt_params),
                                  C.POINTER(C.c_uint32), u32, FP]
     lib.rt_intersect.argtypes = [vp, C.c_int, FP, u32, C.POINTER(C.c_int32), FP, FP]

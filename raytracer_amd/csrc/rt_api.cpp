@@ -50,7 +50,7 @@ struct PassCounters {                 // one per pass, zeroed by one memset per 
 
 #define RT_MAX_PASSES 4096
 #define RT_PASS_SAMPLES (4u << 20)    // level-0 samples per pass
-#define RT_POOL_FACTOR 3u             // node pool = 3x the pass size (level 0 + 2x for all deeper levels)
+#define RT_POOL_FACTOR 6u             // node pool = 6x the pass size when materials bounce (level 0 + 5x for deeper levels)
 #define RT_MAX_TIMED 2048
 #define RT_LEVEL_GRID 4096u           // workgroups of a level >= 1 launch (grid-stride over the device-side count)
 
@@ -225,11 +225,11 @@ static int ensure_workspace(rt_scene* s, uint32_t n0) {
     if (n0 <= s->ws_n0) return RT_OK;
     hipFree(s->node_a); hipFree(s->node_b); hipFree(s->rays);
     s->node_a = nullptr; s->node_b = nullptr; s->rays = nullptr; s->ws_n0 = 0; s->pool_cap = 0;
-    const uint64_t cap = uint64_t(n0) * RT_POOL_FACTOR;
+    const uint64_t cap = uint64_t(n0) * (s->has_bounce ? RT_POOL_FACTOR : 1u);
     if (cap > 0xFFFFFFF0ull) { rt_set_error("pass too large"); return RT_ERR_LIMIT; }
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->node_a), cap * sizeof(float4)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->node_b), cap * sizeof(uint4)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->rays), (cap - n0) * 2 * sizeof(float4)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->rays), std::max<uint64_t>(cap - n0, 1) * 2 * sizeof(float4)));
     s->ws_n0 = n0;
     s->pool_cap = uint32_t(cap);
     return RT_OK;
@@ -504,7 +504,7 @@ extern "C" int rt_render_tiles_device(rt_scene* s, const rt_camera* cam, const r
 }
 
 extern "C" int rt_untile_device(int device, uint32_t W, uint32_t H, uint32_t tw, uint32_t th, uint32_t n_parts,
-                                const uint8_t* d_tiles, uint8_t* d_bgr, void* stream) {
+                                uint32_t part_stride_tiles, const uint8_t* d_tiles, uint8_t* d_bgr, void* stream) {
     if (!d_tiles || !d_bgr || !tw || !th || !n_parts || !W || !H) { rt_set_error("bad argument"); return RT_ERR_INVALID; }
     HIP_TRY(hipSetDevice(device));
     UntileArgs U{};
@@ -512,6 +512,7 @@ extern "C" int rt_untile_device(int device, uint32_t W, uint32_t H, uint32_t tw,
     U.tiles_x = (W + tw - 1) / tw;
     U.n_tiles = U.tiles_x * ((H + th - 1) / th);
     U.n_parts = n_parts;
+    U.part_stride = part_stride_tiles;
     launch_untile(U, d_tiles, d_bgr, static_cast<hipStream_t>(stream));
     HIP_TRY(hipGetLastError());
     return RT_OK;
@@ -580,27 +581,17 @@ extern "C" int rt_occluded(rt_scene* s, const float* rays, const float* max_dist
     return RT_OK;
 }
 
-extern "C" int rt_trace(rt_scene* s, const rt_params* prm, const float* rays, uint32_t n, float* rgb, rt_stats* stats) {
-    if (!s || !prm || !rays || !rgb) { rt_set_error("null argument"); return RT_ERR_INVALID; }
-    if (prm->max_depth < 0 || prm->max_depth >= RT_MAX_LEVELS) { rt_set_error("max_depth %d outside [0,%d]", prm->max_depth, RT_MAX_LEVELS - 1); return RT_ERR_LIMIT; }
-    if (stats) std::memset(stats, 0, sizeof *stats);
-    if (n == 0) return RT_OK;
-    if (n > RT_PASS_SAMPLES) { rt_set_error("rt_trace takes at most %u rays per call", RT_PASS_SAMPLES); return RT_ERR_LIMIT; }
-    HIP_TRY(hipSetDevice(s->device));
-    int rc = ensure_workspace(s, (n + 63u) & ~63u);
-    if (rc != RT_OK) return rc;
-    DevBuf dr, dout;
-    if (dr.alloc(sizeof(float) * 6 * n) || dout.alloc(sizeof(float) * 3 * n)) { rt_set_error("hipMalloc failed"); return RT_ERR_DEVICE; }
-    HIP_TRY(hipMemcpy(dr.p, rays, sizeof(float) * 6 * n, hipMemcpyHostToDevice));
+// One chunk of rt_trace: rays [first, first+n) at level 0. Sets *overflow instead of failing.
+static int trace_chunk(rt_scene* s, const rt_params* prm, const float* d_rays, uint32_t n, float* d_rgb, rt_stats* stats,
+                       bool* overflow) {
     hipStream_t st = s->stream;
-    // the pool is sized for the workspace's pass; with n rays at level 0 the remaining entries serve deeper levels
     HIP_TRY(hipMemsetAsync(s->d_counters, 0, sizeof(PassCounters), st));
     LevelArgs A;
     std::memset(&A, 0, sizeof A);
-    A.n0 = n; A.max_depth = prm->max_depth; A.spp = 1; A.pool_cap = s->pool_cap;
+    A.n0 = n; A.max_depth = prm->max_depth; A.spp = 1;
     A.counters = s->d_counters->level; A.overflow = &s->d_counters->overflow; A.shadow_count = &s->d_counters->shadow;
     A.work = s->d_counters->work;
-    A.node_a = s->node_a; A.node_b = s->node_b; A.user_rays = dr.as<float>();
+    A.node_a = s->node_a; A.node_b = s->node_b; A.user_rays = d_rays;
     // pool entry i >= n0 keeps its ray at rays[2*(i-n0)]; the ray array holds pool_cap - ws_n0 entries, so with
     // n0 = n <= ws_n0 the usable pool shrinks accordingly
     A.rays = s->rays;
@@ -613,22 +604,51 @@ extern "C" int rt_trace(rt_scene* s, const rt_params* prm, const float* rays, ui
     }
     for (int lv = levels - 1; lv >= 1; --lv) { A.level = lv; launch_fold(s->d, A, 1024, st); }
     A.level = 0;
-    launch_resolve_rgb(s->d, A, dout.as<float>(), st);
+    launch_resolve_rgb(s->d, A, d_rgb, st);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(s->h_counters, s->d_counters, sizeof(PassCounters), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (s->h_counters[0].overflow) { rt_set_error("bounce queue overflow: pass fewer rays per rt_trace call"); return RT_ERR_OVERFLOW; }
-    HIP_TRY(hipMemcpy(rgb, dout.p, sizeof(float) * 3 * n, hipMemcpyDeviceToHost));
-    if (stats) {
-        const PassCounters& pc = s->h_counters[0];
-        stats->level_rays[0] = n;
-        for (int lv = 1; lv < RT_MAX_LEVELS; ++lv) stats->level_rays[lv] = pc.level[lv];
-        for (int lv = 0; lv < RT_MAX_LEVELS; ++lv) stats->trace_calls += stats->level_rays[lv];
-        stats->shadow_rays = pc.shadow;
-        stats->passes = 1;
-        s->last_work.nodes_visited = pc.work[0]; s->last_work.tris_tested = pc.work[1];
-        s->last_work.spheres_tested = pc.work[2]; s->last_work.planes_tested = pc.work[3];
+    const PassCounters& pc = s->h_counters[0];
+    *overflow = pc.overflow != 0;
+    if (!*overflow && stats) {
+        stats->level_rays[0] += n;
+        for (int lv = 1; lv < RT_MAX_LEVELS; ++lv) stats->level_rays[lv] += pc.level[lv];
+        stats->shadow_rays += pc.shadow;
+        stats->passes += 1;
+        s->last_work.nodes_visited += pc.work[0]; s->last_work.tris_tested += pc.work[1];
+        s->last_work.spheres_tested += pc.work[2]; s->last_work.planes_tested += pc.work[3];
     }
+    return RT_OK;
+}
+
+extern "C" int rt_trace(rt_scene* s, const rt_params* prm, const float* rays, uint32_t n, float* rgb, rt_stats* stats) {
+    if (!s || !prm || !rays || !rgb) { rt_set_error("null argument"); return RT_ERR_INVALID; }
+    if (prm->max_depth < 0 || prm->max_depth >= RT_MAX_LEVELS) { rt_set_error("max_depth %d outside [0,%d]", prm->max_depth, RT_MAX_LEVELS - 1); return RT_ERR_LIMIT; }
+    if (stats) std::memset(stats, 0, sizeof *stats);
+    if (n == 0) return RT_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    uint32_t chunk = std::min<uint32_t>(n, RT_PASS_SAMPLES);
+    int rc = ensure_workspace(s, (chunk + 63u) & ~63u);
+    if (rc != RT_OK) return rc;
+    DevBuf dr, dout;
+    if (dr.alloc(sizeof(float) * 6 * size_t(n)) || dout.alloc(sizeof(float) * 3 * size_t(n))) { rt_set_error("hipMalloc failed"); return RT_ERR_DEVICE; }
+    HIP_TRY(hipMemcpy(dr.p, rays, sizeof(float) * 6 * size_t(n), hipMemcpyHostToDevice));
+    s->last_work = rt_work{};
+    for (uint32_t done = 0; done < n;) {
+        const uint32_t cnt = std::min(chunk, n - done);
+        bool overflow = false;
+        rc = trace_chunk(s, prm, dr.as<float>() + 6 * size_t(done), cnt, dout.as<float>() + 3 * size_t(done), stats, &overflow);
+        if (rc != RT_OK) return rc;
+        if (overflow) {        // the ray trees of this chunk need more pool than it has: halve the chunk and redo it
+            if (chunk <= 64) { rt_set_error("bounce queue overflow on a 64-ray chunk"); return RT_ERR_OVERFLOW; }
+            chunk = (chunk / 2 + 63u) & ~63u;
+            if (stats) stats->retries += 1;
+            continue;
+        }
+        done += cnt;
+    }
+    HIP_TRY(hipMemcpy(rgb, dout.p, sizeof(float) * 3 * size_t(n), hipMemcpyDeviceToHost));
+    if (stats) for (int lv = 0; lv < RT_MAX_LEVELS; ++lv) stats->trace_calls += stats->level_rays[lv];
     return RT_OK;
 }
 

@@ -40,7 +40,7 @@ __device__ __forceinline__ float dot(V3 a, V3 b) { return (a.x * b.x) + (a.y * b
 // reference src/container.h:151-158
 __device__ __forceinline__ V3 cross(V3 u, V3 v) { return mk(u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x); }
 // reference src/container.h:140-142: double sqrt of the float dot, narrowed == correctly rounded sqrtf
-__device__ __forceinline__ float length(V3 a) { return __fsqrt_rn(dot(a, a)); }
+__device__ __forceinline__ float length(V3 a) { return sqrtf(dot(a, a)); }
 // reference src/container.h:144-146
 __device__ __forceinline__ V3 normalize(V3 a) { return a * (1.0f / length(a)); }
 __device__ __forceinline__ bool isnan3(V3 a) { return isnan(a.x) || isnan(a.y) || isnan(a.z); }
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace_level(DScene S, LevelArgs A)
                         n = n1 / n2;
                         sinSqrPhit = n * n * (1 - cosI * cosI);
                         if (sinSqrPhit <= 1) {
-                            cosT = __fsqrt_rn(1 - sinSqrPhit);
+                            cosT = sqrtf(1 - sinSqrPhit);
                             const float Rorth = (n1 * cosI - n2 * cosT) / (n1 * cosI + n2 * cosT);
                             const float Rpar = (n2 * cosI - n1 * cosT) / (n2 * cosI + n1 * cosT);
                             rCoef = (Rorth * Rorth + Rpar * Rpar) / 2;
@@ -609,8 +609,9 @@ __global__ __launch_bounds__(256) void k_untile(UntileArgs U, const uint8_t* __r
     const uint32_t T = ty * U.tiles_x + tx;
     const uint32_t part = T % U.n_parts, j = T / U.n_parts;
     // tiles of parts 0..part-1 come first: part q owns ceil((n_tiles - q) / n_parts) tiles
-    uint64_t before = 0;
-    for (uint32_t q = 0; q < part; ++q) before += (U.n_tiles - q + U.n_parts - 1) / U.n_parts;
+    uint64_t before = (uint64_t)part * U.part_stride;
+    if (U.part_stride == 0)
+        for (uint32_t q = 0; q < part; ++q) before += (U.n_tiles - q + U.n_parts - 1) / U.n_parts;
     const uint64_t src = (((before + j) * U.tile_h + (y % U.tile_h)) * U.tile_w + (x % U.tile_w)) * 3u;
     const uint64_t dst = p * 3u;
     out[dst] = tiles[src]; out[dst + 1] = tiles[src + 1]; out[dst + 2] = tiles[src + 2];

@@ -68,7 +68,8 @@ struct LevelArgs {
 };
 
 struct UntileArgs {
-    uint32_t W, H, tile_w, tile_h, tiles_x, n_tiles, n_parts, pad;
+    uint32_t W, H, tile_w, tile_h, tiles_x, n_tiles, n_parts;
+    uint32_t part_stride;   // tile slots between parts; 0 = packed
 };
 
 void launch_trace_level(int src, bool count, const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st);

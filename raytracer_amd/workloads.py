@@ -1,0 +1,135 @@
+"""The scenes BASELINE.json's configs name, built from the reference's own scene files' values
+(/root/reference/scene.yaml and scene_exp.yaml, cited per item) with the procedural mesh of meshgen.py where
+the reference points at a .ply that does not ship with it.
+"""
+import os
+import tempfile
+
+import numpy as np
+
+from . import meshgen
+from .scene import DEFAULT_AA, FlatScene, Mesh, Params, material, reference_camera
+
+# scene.yaml:2-8 colours
+GLASS_RGB = (0.01, 0.1, 1.0)
+WHITE, LIGHT_GRAY = 1.0, 0.8
+
+
+def yaml_materials(shadows_only=False):
+    """scene.yaml:10-73. shadows_only clears every reflective/refractive flag (BASELINE configs 2 and 3)."""
+    m = {
+        "glass": dict(color=GLASS_RGB, ka=0.1, kd=0.1, ks=0.2, kr=0.8, kt=0.8, specRefExp=8, refractiveIdx=1.5,
+                      reflective=True, refractive=False),
+        "glass2": dict(color=GLASS_RGB, ka=0, kd=0, ks=0.8, kr=0.2, kt=0.8, specRefExp=8, refractiveIdx=1.5,
+                       reflective=True, refractive=True),
+        "porcelan": dict(color=WHITE, ka=0.2, kd=0.5, ks=0.7, kr=0.3, kt=0, specRefExp=8, refractiveIdx=0,
+                         reflective=True),
+        "mirror": dict(color=WHITE, ka=0, kd=0, ks=0, kr=1, kt=1, specRefExp=8, refractiveIdx=0, reflective=True),
+        "m1": dict(color=LIGHT_GRAY, ka=0.1, kd=0.7, ks=0, kr=0.3, kt=0, specRefExp=8, refractiveIdx=0,
+                   reflective=False),
+        "m2": dict(color=WHITE, ka=0.1, kd=0.7, ks=0.4),
+        "blue": dict(color=(0, 0, 1)),
+        "red": dict(color=(1, 0, 0)),
+        "green": dict(color=(0, 1, 0)),
+    }
+    out = {}
+    for k, v in m.items():
+        if shadows_only:
+            v = dict(v, reflective=False, refractive=False)
+        out[k] = material(**v)
+    return out
+
+
+def add_yaml_lights(fs):
+    """scene.yaml:75-81."""
+    fs.add_light((0.0, 3.0, -7.5), WHITE, 3.0)
+    fs.add_light((0.0, 0.0, -1.0), WHITE, 10.0)
+
+
+def add_yaml_spheres(fs, mats, third="glass"):
+    """scene.yaml:85-96."""
+    fs.add_sphere((0.0, 0.0, -8.0), 1.0, mats["mirror"])
+    fs.add_sphere((2.0, 0.25, -8.0), 0.75, mats["m1"])
+    fs.add_sphere((-2.5, 2.0, -5.0), 1.0, mats[third])
+
+
+def add_yaml_planes(fs, mats):
+    """scene.yaml:106-125."""
+    fs.add_plane((0.0, 0.0, 1.0), 12.0, mats["green"])
+    fs.add_plane((1.0, 0.0, 0.0), 4.0, mats["red"])
+    fs.add_plane((-1.0, 0.0, 0.0), 4.0, mats["blue"])
+    fs.add_plane((0.0, 1.0, 0.0), 4.0, mats["blue"])
+    fs.add_plane((0.0, -1.0, 0.0), 4.0, mats["red"])
+
+
+_mesh_cache = {}
+
+
+def yaml_mesh(n_subdiv, seed=2, cache_dir=None):
+    """The mesh object of scene.yaml:98-104 (scale 20, rotation y 0.5236, translation (-1.5,-1,-6)) with a
+    procedural 20*n*n-face blob in place of bun_zipper*.ply, taken through the PLY loader + transform chain of
+    the C++ host surface exactly as the reference's loader would."""
+    key = (n_subdiv, seed)
+    if key in _mesh_cache:
+        return _mesh_cache[key]
+    d = cache_dir or tempfile.gettempdir()
+    path = os.path.join(d, f"rtamd_blob_n{n_subdiv}_s{seed}_{os.getpid()}.ply")
+    V, F = meshgen.blob(n_subdiv, seed=seed)
+    meshgen.write_ply(path, V, F)
+    try:
+        mesh = Mesh.load_ply(path, rotation=(0.0, 0.5235987755982988, 0.0), scale=20.0,
+                             translation=(-1.5, -1.0, -6.0))
+    finally:
+        os.unlink(path)
+    _mesh_cache[key] = mesh
+    return mesh
+
+
+def scene_analytic(third="glass", shadows_only=False):
+    """Analytic part of scene.yaml: 3 spheres + 5 planes + 2 lights, no mesh (SURVEY.md §8c known answers)."""
+    fs = FlatScene()
+    mats = yaml_materials(shadows_only)
+    add_yaml_spheres(fs, mats, third)
+    add_yaml_planes(fs, mats)
+    add_yaml_lights(fs)
+    return fs
+
+
+def scene_bunny(n_subdiv=59, shadows_only=False, spheres=True, third="glass"):
+    """scene.yaml as shipped, objects in file order: 3 spheres, the mesh (porcelan), 5 planes.
+    n_subdiv=59 -> 69,620 faces (bun_zipper.ply has 69,451); n_subdiv=29 -> 16,820 (bun_zipper_res2: 16,301)."""
+    fs = FlatScene()
+    mats = yaml_materials(shadows_only)
+    if spheres:
+        add_yaml_spheres(fs, mats, third)
+    fs.add_mesh(yaml_mesh(n_subdiv), mats["porcelan"])
+    add_yaml_planes(fs, mats)
+    add_yaml_lights(fs)
+    return fs
+
+
+def aa_grid(n):
+    """n x n stratified grid minus (0,0) (the corner ray is always cast): n*n samples per pixel."""
+    pts = [((i % n) / n, (i // n) / n) for i in range(1, n * n)]
+    return pts
+
+
+WORKLOADS = {
+    # name: (scene factory, width, height, aa pattern, max_depth)
+    # BASELINE config 1 at the reference's own resolution, with the low-res mesh class
+    "c1_scene_yaml_800x600": (lambda: scene_bunny(29), 800, 600, (), 10),
+    # BASELINE config 2
+    "c2_analytic_1080p_4spp": (lambda: scene_analytic(shadows_only=True), 1920, 1080,
+                               ((0.5, 0.5), (0.25, 0.75), (0.75, 0.25)), 10),
+    # BASELINE config 3 (strict reading: Phong + hard shadows only)
+    "c3_bunny_1080p_shadows": (lambda: scene_bunny(59, shadows_only=True, spheres=False), 1920, 1080, (), 10),
+    # The metric's "bunny scene 1920x1080" with the scene file's own materials (reflections + shadows): bench default
+    "bunny_1080p": (lambda: scene_bunny(59), 1920, 1080, (), 10),
+    # BASELINE config 4
+    "c4_bunny_glass_4k_16spp": (lambda: scene_bunny(59, third="glass2"), 3840, 2160, aa_grid(4), 8),
+}
+
+
+def make_workload(name):
+    factory, W, H, aa, depth = WORKLOADS[name]
+    return factory(), reference_camera(W, H), Params(max_depth=depth, aa=aa)
