@@ -424,7 +424,10 @@ public:
            std::vector<Point2D> pattern = defaultAntiAliasingPattern())
         : eye(eye_), up(up_), at(at_), aspectRatio(aspect), fov(fov_), imWidth(W), imHeight(H),
           antiAliasingPattern(std::move(pattern)) {
-        up.normalize(); at.normalize(); right = cross_product(at, up);      // ref :34-36
+        up.normalize(); at.normalize();                                     // ref :34-35
+        // ref :36 writes cross_product(at, up) inside a constructor whose PARAMETERS are also called at/up, so the
+        // un-normalised arguments are crossed, not the members just normalised. Kept: rays depend on it.
+        right = cross_product(at_, up_);
     }
     static std::vector<Point2D> defaultAntiAliasingPattern() {             // ref :40-50
         return {Point2D(0.5f, 0.5f), Point2D(0.25f, 0.25f), Point2D(0.75f, 0.25f), Point2D(0.75f, 0.75f),

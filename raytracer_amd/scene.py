@@ -69,6 +69,22 @@ def make_camera(width, height, fov=60.0, eye=(0, 0, 0), up=(0, 1, 0), at=(0, 0, 
     return cam
 
 
+def camera_to_array(cam):
+    return np.array([*cam.eye, *cam.up, *cam.right, *cam.at, cam.aspectRatio, cam.fov, cam.imWidth, cam.imHeight],
+                    dtype=np.float64)
+
+
+def camera_from_array(a):
+    cam = rt_camera()
+    cam.eye[:] = [float(np.float32(x)) for x in a[0:3]]
+    cam.up[:] = [float(np.float32(x)) for x in a[3:6]]
+    cam.right[:] = [float(np.float32(x)) for x in a[6:9]]
+    cam.at[:] = [float(np.float32(x)) for x in a[9:12]]
+    cam.aspectRatio, cam.fov = float(np.float32(a[12])), float(np.float32(a[13]))
+    cam.imWidth, cam.imHeight = int(a[14]), int(a[15])
+    return cam
+
+
 def reference_camera(width, height):
     """The camera main() builds (reference src/raytracer.cpp:674-689) at another resolution."""
     return make_camera(width, height, fov=60.0, move=(-0.5, 0, -0.25))
@@ -171,6 +187,63 @@ class FlatScene:
     @property
     def num_faces(self):
         return sum(m.num_faces for m in self.meshes)
+
+    def to_arrays(self):
+        """Plain numpy arrays (for .npz fixtures): every field of the flat scene, nothing else."""
+        mats = np.array([[*m.color, m.ka, m.kd, m.ks, m.kr, m.kt, m.specRefExp, m.refractiveIdx, m.reflective,
+                          m.refractive] for m in self.materials], dtype=np.float32).reshape(-1, 12)
+        d = {
+            "objects": np.array(self.objects, dtype=np.int64).reshape(-1, 3),
+            "spheres": np.array([[*s.center, s.radius] for s in self.spheres], dtype=np.float32).reshape(-1, 4),
+            "planes": np.array([[p.a, p.b, p.c, p.d] for p in self.planes], dtype=np.float32).reshape(-1, 4),
+            "materials": mats,
+            "lights": np.array([[*l.pos, *l.color] for l in self.lights], dtype=np.float32).reshape(-1, 6),
+            "mesh_faces": np.array([m.num_faces for m in self.meshes], dtype=np.int64),
+            "mesh_bb": np.array([m.bb for m in self.meshes], dtype=np.float32).reshape(-1, 4),
+        }
+        for k, name in enumerate(("v0", "v1", "v2", "n0", "n1", "n2")):
+            d[name] = (np.concatenate([m.v[k] for m in self.meshes]) if self.meshes
+                       else np.zeros((0, 3), np.float32))
+        return d
+
+    @staticmethod
+    def from_arrays(d):
+        fs = FlatScene()
+        mats = []
+        for r in d["materials"]:
+            m = rt_material()
+            m.color[:] = [float(x) for x in r[:3]]
+            m.ka, m.kd, m.ks, m.kr, m.kt, m.specRefExp, m.refractiveIdx = [float(x) for x in r[3:10]]
+            m.reflective, m.refractive = int(r[10]), int(r[11])
+            mats.append(m)
+        for r in d["spheres"]:
+            s = rt_sphere()
+            s.center[:] = [float(x) for x in r[:3]]
+            s.radius = float(r[3])
+            fs.spheres.append(s)
+        for r in d["planes"]:
+            p = rt_plane()
+            p.a, p.b, p.c, p.d = [float(x) for x in r]
+            fs.planes.append(p)
+        off = 0
+        for nf, bb in zip(d["mesh_faces"], d["mesh_bb"]):
+            nf = int(nf)
+            mesh = Mesh(*[d[k][off:off + nf] for k in ("v0", "v1", "v2", "n0", "n1", "n2")], bb)
+            md = rt_model()
+            md.first_face, md.num_faces = off, nf
+            md.bb_center[:] = [float(x) for x in bb[:3]]
+            md.bb_radius = float(bb[3])
+            fs.meshes.append(mesh)
+            fs.models.append(md)
+            off += nf
+        fs.materials = mats
+        fs.objects = [(int(t), int(i), int(m)) for t, i, m in d["objects"]]
+        for r in d["lights"]:
+            l = rt_light()
+            l.pos[:] = [float(x) for x in r[:3]]
+            l.color[:] = [float(x) for x in r[3:]]
+            fs.lights.append(l)
+        return fs
 
     def c_struct(self):
         if self._c is not None:
