@@ -1,0 +1,68 @@
+"""The N > 1 path on CPU: two gloo ranks each "render" the tiles they own (the oracle stands in for the device,
+writing the same tile-major layout rt_render_tiles_device produces), rank 0 gathers with torch.distributed and
+scatters the tiles back; the frame must be byte-identical to the single-rank frame."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import gold, sub
+from raytracer_amd import cabi, tiling
+from raytracer_amd.scene import FlatScene, Params, camera_from_array
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, tw, th, result_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    g = gold("frames.npz")
+    fs = FlatScene.from_arrays(sub(g, "mesh_scene_"))
+    cam = camera_from_array(g["cam_small"])
+    W, H = cam.imWidth, cam.imHeight
+    orc = O.Oracle(fs)
+    slot = tiling.tiles_owned(W, H, tw, th, 0, world)
+    mine = np.zeros((slot, th, tw, 3), np.uint8)
+    scratch = np.zeros((H, W, 3), np.uint8)
+    for j, x0, y0, w, h in tiling.owned_tile_rects(W, H, tw, th, rank, world):
+        orc.render(cam, Params(), rect=(x0, y0, w, h), out=scratch)
+        mine[j, :h, :w] = scratch[y0:y0 + h, x0:x0 + w]
+    t = torch.from_numpy(mine.reshape(-1))
+    gathered = [torch.zeros_like(t) for _ in range(world)] if rank == 0 else None
+    dist.gather(t, gathered, dst=0)
+    if rank == 0:
+        frame = tiling.untile([x.numpy() for x in gathered], W, H, tw, th)
+        np.save(result_path, frame)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_tile_gather_is_byte_identical(tmp_path, oracle_mod):
+    tw, th = 24, 16           # 160x120 -> 7 x 8 tiles, ragged right edge (160 = 6*24 + 16)
+    out = str(tmp_path / "frame.npy")
+    mp.spawn(_worker, args=(2, _free_port(), tw, th, out), nprocs=2, join=True)
+    frame = np.load(out)
+    assert np.array_equal(frame, gold("frames.npz")["mesh_d10_1"])
+
+
+def test_tiles_owned_matches_the_library():
+    lib = cabi.load()
+    for (W, H, tw, th) in [(1920, 1080, 32, 32), (160, 120, 24, 16), (7, 5, 8, 8), (800, 600, 64, 16)]:
+        for n in (1, 2, 3, 4, 8):
+            total = 0
+            for p in range(n):
+                k = lib.rt_tiles_owned(W, H, tw, th, p, n)
+                assert k == tiling.tiles_owned(W, H, tw, th, p, n)
+                total += k
+            tx, ty = tiling.tile_grid(W, H, tw, th)
+            assert total == tx * ty
+    assert lib.rt_tiles_owned(10, 10, 8, 8, 3, 2) == 0       # part >= n_parts
+    assert lib.rt_tiles_owned(10, 10, 0, 8, 0, 1) == 0
