@@ -45,20 +45,29 @@ def cpu_baseline(fs, cam, params, dev, np):
     cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("OMP_NUM_THREADS", "16")), 16)
     backend = O.Reference(fs) if kind == "reference" else O.Oracle(fs)
     W, H = cam.imWidth, cam.imHeight
-    strips = [(int(W * (k + 0.5) / 8), 0, 4, H) for k in range(8)]
-    rays = 0
-    secs = 0.0
-    same = True
-    for rect in strips:
-        g, st = dev.render(cam, params, rect=rect)
-        rays += st.trace_calls + st.shadow_rays
-        t = time.time()
-        c, _ = backend.render(cam, params, rect=rect, threads=cores)
-        secs += time.time() - t
-        d = np.abs(g.astype(np.int16) - c.astype(np.int16)).max(axis=2)
-        same = same and float((d <= 1).mean()) >= 0.999
+
+    def run(width):
+        strips = [(min(W - width, int(W * (k + 0.5) / 8)), 0, width, H) for k in range(8)]
+        rays, secs, same = 0, 0.0, True
+        for rect in strips:
+            g, st = dev.render(cam, params, rect=rect)
+            rays += st.trace_calls + st.shadow_rays
+            t = time.time()
+            c, _ = backend.render(cam, params, rect=rect, threads=cores)
+            secs += time.time() - t
+            x0, y0, w, h = rect
+            d = np.abs(g[:, x0:x0 + w].astype(np.int16) - c[:, x0:x0 + w].astype(np.int16)).max(axis=2)
+            same = same and float((d <= 1).mean()) >= 0.999
+        return rays, secs, same
+
+    width = 4
+    rays, secs, same = run(width)                    # probe, then size the sample to about 15 s of CPU wall time
+    target = int(width * 15.0 / max(secs, 1e-3))
+    if target > width:
+        width = max(4, min(W // 8, 160, target))
+        rays, secs, same = run(width)
     return {"value": rays / secs / 1e6, "unit": "Mrays/s", "cores": cores, "kind": kind,
-            "sample": f"8 strips of 4x{H} px of the same frame ({rays} rays, {secs:.1f} s CPU wall)",
+            "sample": f"8 strips of {width}x{H} px of the same frame, evenly spread ({rays} rays, {secs:.1f} s CPU wall)",
             "gpu_matches_cpu_on_sample": bool(same)}
 
 
