@@ -129,66 +129,81 @@ __device__ __forceinline__ bool tri_isect(V3 v0, V3 e1, V3 e2, const Ray& ray, f
 // (entry [level][lane]: conflict-free, lanes of a wave hit distinct banks). Depth <= RT_BVH_MAX_DEPTH by
 // construction (bvh_build.cpp), so 32 entries can never overflow.
 // ---------------------------------------------------------------------------------------------------------
-#define RT_STACK 32
+#define RT_STACK 32   // RT_BVH_MAX_DEPTH deferred children + the sentinel
 
 struct Work { uint32_t nodes, tris, spheres, planes; };
 
-__device__ __forceinline__ float slab(const float* lo, const float* hi, V3 o, V3 inv, float tmax, bool& hit) {
-    const float tx0 = (lo[0] - o.x) * inv.x, tx1 = (hi[0] - o.x) * inv.x;
-    const float ty0 = (lo[1] - o.y) * inv.y, ty1 = (hi[1] - o.y) * inv.y;
-    const float tz0 = (lo[2] - o.z) * inv.z, tz1 = (hi[2] - o.z) * inv.z;
-    // fminf/fmaxf return the non-NaN operand, so a 0*inf axis (origin on a slab plane, zero direction) never culls
-    float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), 0.0f));
-    float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tmax));
+// Ray/box slab test for culling only (never decides a hit): t = lo*inv - o*inv as one FMA per plane. Its error
+// (<= 2^-24 |o| in space) is far inside the 2e-5 relative padding of the boxes. fminf/fmaxf return the non-NaN
+// operand, so an axis whose products are inf-inf / 0*inf (zero direction component) simply does not cull.
+__device__ __forceinline__ float slab(float lox, float loy, float loz, float hix, float hiy, float hiz, V3 inv, V3 ood,
+                                      float tmax, bool& hit) {
+    const float tx0 = __builtin_fmaf(lox, inv.x, -ood.x), tx1 = __builtin_fmaf(hix, inv.x, -ood.x);
+    const float ty0 = __builtin_fmaf(loy, inv.y, -ood.y), ty1 = __builtin_fmaf(hiy, inv.y, -ood.y);
+    const float tz0 = __builtin_fmaf(loz, inv.z, -ood.z), tz1 = __builtin_fmaf(hiz, inv.z, -ood.z);
+    const float tn = fmaxf(fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fminf(tz0, tz1)), 0.0f);
+    float tf = fminf(fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1)), tmax);
     tf *= 1.0000005f;   // conservative far bound (robust slab test)
     hit = tn <= tf;
     return tn;
 }
 
+__device__ __forceinline__ float safe_rcp(float d) {
+    const float a = fabsf(d) < 1e-30f ? copysignf(1e-30f, d) : d;   // NaN stays NaN: its axis then never culls
+    return 1.0f / a;
+}
+
+#define RT_DONE 0xFFFFFFFFu   // stack sentinel; has the leaf bit set, so the descent loop stops on it too
+
 // ANY = false: closest hit over the model's faces, ties broken by the lower ORIGINAL face index, which is what
 // the reference's ascending strict-< scan keeps (primitives.cpp:376-382). Returns hit; t/u/v/face of the winner.
 // ANY = true : does some face have EPS < t < tmax (the shadow test `hit && tmpdist < ldist`, raytracer.cpp:320-321).
+//
+// Two-phase loop ("while-while"): every lane first descends interior nodes until it holds a leaf, then the lanes
+// test their leaves together. On a 64-wide wave this keeps the node step and the triangle test from being
+// executed back to back for disjoint lane sets in every iteration.
 template <bool ANY, bool COUNT>
 __device__ __forceinline__ bool bvh_traverse(const DScene& S, uint32_t root, const Ray& ray, float tmax, float& best_t,
                                              float& best_u, float& best_v, uint32_t& best_face, uint32_t* stack,
                                              Work& wk) {
-    const V3 inv = mk(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+    // culling direction: a zero (or denormal) component is replaced by +-1e-30 so that lo*inv - o*inv keeps the sign of
+    // lo - o instead of becoming inf - inf; only the box tests use it, the triangle test gets the ray as it is
+    const V3 inv = mk(safe_rcp(ray.d.x), safe_rcp(ray.d.y), safe_rcp(ray.d.z));
+    const V3 ood = mk(ray.o.x * inv.x, ray.o.y * inv.y, ray.o.z * inv.z);
     float best = ANY ? tmax : FLT_MAX;
-    float tcull = best;       // FLT_MAX * (1+eps) would overflow; inf is fine too but keep it finite
+    float tcull = best;
     bool found = false;
     uint32_t face = 0xFFFFFFFFu;
     float bu = 0, bv = 0;
-    int sp = 0;
-    uint32_t cur = root;
-    if (cur == RT_NO_CHILD) return false;
-    for (;;) {
-        if (!(cur & RT_LEAF_BIT)) {
+    stack[0] = RT_DONE;
+    int sp = 1;
+    uint32_t cur = root;       // RT_NO_CHILD == RT_DONE for an empty model
+    while (cur != RT_DONE) {
+        while (!(cur & RT_LEAF_BIT)) {
             const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
             const float4 a = np[0], b = np[1], c = np[2];
             const uint4 r = reinterpret_cast<const uint4*>(np)[3];
             if (COUNT) wk.nodes++;
-            const float lo0[3] = {a.x, a.y, a.z}, hi0[3] = {a.w, b.x, b.y};
-            const float lo1[3] = {b.z, b.w, c.x}, hi1[3] = {c.y, c.z, c.w};
             bool h0, h1;
-            const float t0 = slab(lo0, hi0, ray.o, inv, tcull, h0);
-            const float t1 = slab(lo1, hi1, ray.o, inv, tcull, h1);
+            const float t0 = slab(a.x, a.y, a.z, a.w, b.x, b.y, inv, ood, tcull, h0);
+            const float t1 = slab(b.z, b.w, c.x, c.y, c.z, c.w, inv, ood, tcull, h1);
             if (h0 && h1) {
                 const bool first0 = t0 <= t1;
                 stack[sp * RT_BLOCK] = first0 ? r.y : r.x;
                 ++sp;
                 cur = first0 ? r.x : r.y;
-            } else if (h0) {
-                cur = r.x;
-            } else if (h1) {
-                cur = r.y;
+            } else if (h0 || h1) {
+                cur = h0 ? r.x : r.y;
             } else {
-                if (sp == 0) break;
                 --sp;
                 cur = stack[sp * RT_BLOCK];
             }
-        } else {
+        }
+        if (cur != RT_DONE) {
             const uint32_t start = cur & RT_LEAF_START_MASK;
             const uint32_t cnt = ((cur >> 27) & 15u) + 1u;
+            --sp;
+            cur = stack[sp * RT_BLOCK];
             for (uint32_t i = 0; i < cnt; ++i) {
                 const float4* tp = reinterpret_cast<const float4*>(S.tris + (start + i));
                 const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
@@ -197,16 +212,13 @@ __device__ __forceinline__ bool bvh_traverse(const DScene& S, uint32_t root, con
                 if (tri_isect(f4xyz(q0), f4xyz(q1), f4xyz(q2), ray, t, u, v)) {
                     const uint32_t f = __float_as_uint(q0.w);
                     if (ANY) {
-                        if (t < tmax) return true;
+                        if (t < tmax) { found = true; cur = RT_DONE; }
                     } else if (t < best || (t == best && f < face)) {
                         best = t; bu = u; bv = v; face = f; found = true;
                         tcull = t * 1.000001f;
                     }
                 }
             }
-            if (sp == 0) break;
-            --sp;
-            cur = stack[sp * RT_BLOCK];
         }
     }
     if (!ANY && found) { best_t = best; best_u = bu; best_v = bv; best_face = face; }
