@@ -400,9 +400,19 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace_level(DScene S, LevelArgs A)
     Work wk = {0, 0, 0, 0};
     uint32_t n_shadow = 0;
 
-    for (uint32_t i = begin + blockIdx.x * RT_BLOCK + threadIdx.x; i < ((end - begin + RT_BLOCK - 1) / RT_BLOCK) * RT_BLOCK + begin;
-         i += gridDim.x * RT_BLOCK) {
-        const bool active = i < end;
+    // Rays per wave. Level 0 and large levels fill all 64 lanes. A level with few rays (deep bounces) is spread over
+    // the whole grid instead, R rays per wave: its rays are incoherent, so a wave's time is close to the SUM of its
+    // lanes' paths, and fewer lanes per wave shorten the level's critical path at no cost in total issue slots.
+    uint32_t R = RT_BLOCK;
+    if (SRC == 1) {
+        const uint32_t per = (end - begin + gridDim.x - 1) / gridDim.x;
+        R = per < 1u ? 1u : (per < RT_BLOCK ? per : RT_BLOCK);
+    }
+    const uint32_t n_items = end - begin;
+    const uint32_t n_groups = (n_items + R - 1) / R;
+    for (uint32_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const uint32_t i = begin + grp * R + threadIdx.x;
+        const bool active = threadIdx.x < R && i < end;
         Ray ray;
         ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 0);
         bool valid = active;
