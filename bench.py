@@ -174,6 +174,7 @@ def main():
                        "max_depth": params.c.max_depth, "triangles": fs.num_faces, "objects": len(fs.objects),
                        "lights": len(fs.lights), "rays_per_frame": rays_per_frame,
                        "trace_calls": st.trace_calls, "shadow_rays": st.shadow_rays,
+                       "level_rays": [int(x) for x in st.level_rays[:params.c.max_depth + 1]],
                        "parallelism": "1 GPU" if world == 1 else f"{world} GPUs: {tw}x{th} tiles round-robin, RCCL gather",
                        "mesh": "procedural geodesic blob (no .ply ships with the reference)",
                        "scene_build_s": round(build_s, 3)},
@@ -204,7 +205,8 @@ def main():
                 "trace_kernel_share_of_frame": tk_ms / frame_ms if frame_ms else None,
                 "valu": {"achieved": tfl, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / VALU_PEAK_TFLOPS},
                 "work_per_frame": {"bvh_nodes": work.nodes_visited, "tri_tests": work.tris_tested,
-                                   "sphere_tests": work.spheres_tested, "plane_tests": work.planes_tested},
+                                   "sphere_tests": work.spheres_tested, "plane_tests": work.planes_tested,
+                                   "wave_node_steps": work.wave_node_steps, "wave_tri_steps": work.wave_tri_steps},
             }
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(fs, cam, params, dev, np)

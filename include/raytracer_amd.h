@@ -219,6 +219,8 @@ typedef struct rt_work {
     uint64_t tris_tested;
     uint64_t spheres_tested;
     uint64_t planes_tested;
+    uint64_t wave_node_steps;   /* times a 64-lane wave executed the node step (any lane active) */
+    uint64_t wave_tri_steps;    /* times a wave executed the triangle test                        */
 } rt_work;
 int rt_set_count_work(rt_scene* scene, int enable);
 int rt_get_work(const rt_scene* scene, rt_work* out);

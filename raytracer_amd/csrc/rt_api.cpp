@@ -45,7 +45,7 @@ struct PassCounters {                 // one per pass, zeroed by one memset per 
     uint32_t overflow;
     uint32_t pad[3];
     unsigned long long shadow;
-    unsigned long long work[4];
+    unsigned long long work[6];
 };
 
 #define RT_MAX_PASSES 4096
@@ -386,6 +386,7 @@ static int render_frame(rt_scene* s, const rt_camera* cam, const rt_params* prm,
             stats->shadow_rays += pc.shadow;
             for (int lv = 1; lv < RT_MAX_LEVELS; ++lv) stats->level_rays[lv] += pc.level[lv];
             w.nodes_visited += pc.work[0]; w.tris_tested += pc.work[1]; w.spheres_tested += pc.work[2]; w.planes_tested += pc.work[3];
+            w.wave_node_steps += pc.work[4]; w.wave_tri_steps += pc.work[5];
         }
         s->last_work = w;
         stats->passes = uint32_t(final_recs.size());
@@ -617,6 +618,7 @@ static int trace_chunk(rt_scene* s, const rt_params* prm, const float* d_rays, u
         stats->passes += 1;
         s->last_work.nodes_visited += pc.work[0]; s->last_work.tris_tested += pc.work[1];
         s->last_work.spheres_tested += pc.work[2]; s->last_work.planes_tested += pc.work[3];
+        s->last_work.wave_node_steps += pc.work[4]; s->last_work.wave_tri_steps += pc.work[5];
     }
     return RT_OK;
 }

@@ -131,7 +131,11 @@ __device__ __forceinline__ bool tri_isect(V3 v0, V3 e1, V3 e2, const Ray& ray, f
 // ---------------------------------------------------------------------------------------------------------
 #define RT_STACK 32   // RT_BVH_MAX_DEPTH deferred children + the sentinel
 
-struct Work { uint32_t nodes, tris, spheres, planes; };
+struct Work { uint32_t nodes, tris, spheres, planes, wave_nodes, wave_tris; };
+
+__device__ __forceinline__ uint32_t lane_id();
+// 1 on exactly one active lane of the wave: counts how often the WAVE executes a loop body (COUNT builds)
+__device__ __forceinline__ uint32_t wave_once() { return lane_id() == (uint32_t)(__ffsll((long long)__ballot(1)) - 1) ? 1u : 0u; }
 
 // Ray/box slab test for culling only (never decides a hit): t = lo*inv - o*inv as one FMA per plane. Its error
 // (<= 2^-24 |o| in space) is far inside the 2e-5 relative padding of the boxes. fminf/fmaxf return the non-NaN
@@ -183,7 +187,7 @@ __device__ __forceinline__ bool bvh_traverse(const DScene& S, uint32_t root, con
             const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
             const float4 a = np[0], b = np[1], c = np[2];
             const uint4 r = reinterpret_cast<const uint4*>(np)[3];
-            if (COUNT) wk.nodes++;
+            if (COUNT) { wk.nodes++; wk.wave_nodes += wave_once(); }
             bool h0, h1;
             const float t0 = slab(a.x, a.y, a.z, a.w, b.x, b.y, inv, ood, tcull, h0);
             const float t1 = slab(b.z, b.w, c.x, c.y, c.z, c.w, inv, ood, tcull, h1);
@@ -207,7 +211,7 @@ __device__ __forceinline__ bool bvh_traverse(const DScene& S, uint32_t root, con
             for (uint32_t i = 0; i < cnt; ++i) {
                 const float4* tp = reinterpret_cast<const float4*>(S.tris + (start + i));
                 const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
-                if (COUNT) wk.tris++;
+                if (COUNT) { wk.tris++; wk.wave_tris += wave_once(); }
                 float t, u, v;
                 if (tri_isect(f4xyz(q0), f4xyz(q1), f4xyz(q2), ray, t, u, v)) {
                     const uint32_t f = __float_as_uint(q0.w);
@@ -380,7 +384,7 @@ __device__ __forceinline__ bool map_pixel(const PixelMap& pm, uint64_t q, uint32
 //   SRC 2: level 0, rays supplied by the caller (rt_trace)
 // ---------------------------------------------------------------------------------------------------------
 template <int SRC, bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) void k_trace_level(DScene S, LevelArgs A) {
+__global__ __launch_bounds__(RT_BLOCK, 4) void k_trace_level(DScene S, LevelArgs A) {
     __shared__ uint32_t lds_stack[RT_STACK * RT_BLOCK];
     uint32_t* stack = lds_stack + threadIdx.x;
 
@@ -397,7 +401,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace_level(DScene S, LevelArgs A)
     const uint32_t next_base = end;               // children of this level are appended behind it
     uint32_t* next_count = A.counters + (A.level + 1);
 
-    Work wk = {0, 0, 0, 0};
+    Work wk = {0, 0, 0, 0, 0, 0};
     uint32_t n_shadow = 0;
 
     // Rays per wave. Level 0 and large levels fill all 64 lanes. A level with few rays (deep bounces) is spread over
@@ -556,6 +560,11 @@ __global__ __launch_bounds__(RT_BLOCK) void k_trace_level(DScene S, LevelArgs A)
             atomicAdd(A.work + 2, (unsigned long long)c);
             atomicAdd(A.work + 3, (unsigned long long)d);
         }
+        const uint32_t e = wave_sum(wk.wave_nodes), f = wave_sum(wk.wave_tris);
+        if (lane_id() == 0) {
+            atomicAdd(A.work + 4, (unsigned long long)e);
+            atomicAdd(A.work + 5, (unsigned long long)f);
+        }
     }
 }
 
@@ -659,7 +668,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_intersect(DScene S, int object, co
     if (i >= n) return;
     Ray ray;
     ray.o = ld3(rays + 6 * (size_t)i); ray.d = ld3(rays + 6 * (size_t)i + 3);
-    Work wk = {0, 0, 0, 0};
+    Work wk = {0, 0, 0, 0, 0, 0};
     float d = 0;
     V3 nrm = mk(0, 0, 0);
     int hit = -1;
@@ -687,7 +696,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_occluded(DScene S, const float* __
     if (i >= n) return;
     Ray ray;
     ray.o = ld3(rays + 6 * (size_t)i); ray.d = ld3(rays + 6 * (size_t)i + 3);
-    Work wk = {0, 0, 0, 0};
+    Work wk = {0, 0, 0, 0, 0, 0};
     float tmp = 0;
     occ[i] = occluded<false>(S, ray, max_dist[i], tmp, stack, wk) ? 1 : 0;
 }
