@@ -131,17 +131,24 @@ def main():
         owned = lib.rt_tiles_owned(W, H, tw, th, rank, world)
         slot = lib.rt_tiles_owned(W, H, tw, th, 0, world)       # part 0 owns the most tiles
         mine = torch.zeros((slot * tw * th * 3,), dtype=torch.uint8, device="cuda")
-        gathered = [torch.zeros_like(mine) for _ in range(world)] if rank == 0 else None
         allt = torch.zeros((world * slot * tw * th * 3,), dtype=torch.uint8, device="cuda") if rank == 0 else None
+        gathered = list(allt.chunk(world)) if rank == 0 else None     # the gather lands directly in the untile input
 
     def step():
         if world == 1:
             dev.render_device(cam, params, frame.data_ptr(), stream=stream)
         else:
             dev.render_tiles_device(cam, params, (tw, th), rank, world, mine.data_ptr(), stream=stream)
-            dist.gather(mine, gathered, dst=0)
+            if args.backend == "nccl":
+                dist.gather(mine, gathered, dst=0)
+            else:       # gloo rehearsal: gloo gathers host tensors only
+                torch.cuda.current_stream().synchronize()
+                host = mine.cpu()
+                hg = [torch.zeros_like(host) for _ in range(world)] if rank == 0 else None
+                dist.gather(host, hg, dst=0)
+                if rank == 0:
+                    allt.copy_(torch.cat(hg))
             if rank == 0:
-                torch.cat(gathered, out=allt)
                 cabi.check(lib, lib.rt_untile_device(local, W, H, tw, th, world, slot, C.c_void_p(allt.data_ptr()),
                                                      C.c_void_p(frame.data_ptr()), C.c_void_p(stream)))
 
@@ -159,7 +166,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t
     if world > 1:
-        e = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        e = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(e, op=dist.ReduceOp.MAX)
         elapsed = float(e.item())
 
