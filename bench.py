@@ -213,7 +213,8 @@ def main():
                 "valu": {"achieved": tfl, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / VALU_PEAK_TFLOPS},
                 "work_per_frame": {"bvh_nodes": work.nodes_visited, "tri_tests": work.tris_tested,
                                    "sphere_tests": work.spheres_tested, "plane_tests": work.planes_tested,
-                                   "wave_node_steps": work.wave_node_steps, "wave_tri_steps": work.wave_tri_steps},
+                                   "wave_node_steps": work.wave_node_steps, "wave_tri_steps": work.wave_tri_steps,
+                                   "segment_cycles[fetch,closest,shadow,shade,append,bvh]": list(work.segment_cycles)},
             }
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(fs, cam, params, dev, np)

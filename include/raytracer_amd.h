@@ -221,6 +221,8 @@ typedef struct rt_work {
     uint64_t planes_tested;
     uint64_t wave_node_steps;   /* times a 64-lane wave executed the node step (any lane active) */
     uint64_t wave_tri_steps;    /* times a wave executed the triangle test                        */
+    uint64_t segment_cycles[6]; /* diagnostic: wave cycles in ray fetch, closest hit, shadow tests, shading,
+                                   append+write, and (inside the 2nd/3rd) BVH traversal           */
 } rt_work;
 int rt_set_count_work(rt_scene* scene, int enable);
 int rt_get_work(const rt_scene* scene, rt_work* out);

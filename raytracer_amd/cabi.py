@@ -83,7 +83,8 @@ class rt_bvh_info(C.Structure):
 class rt_work(C.Structure):
     _fields_ = [("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64),
                 ("spheres_tested", C.c_uint64), ("planes_tested", C.c_uint64),
-                ("wave_node_steps", C.c_uint64), ("wave_tri_steps", C.c_uint64)]
+                ("wave_node_steps", C.c_uint64), ("wave_tri_steps", C.c_uint64),
+                ("segment_cycles", C.c_uint64 * 6)]
 
 
 def fptr(a):

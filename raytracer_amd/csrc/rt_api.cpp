@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -44,11 +45,11 @@ struct PassCounters {                 // one per pass, zeroed by one memset per 
     uint32_t level[RT_MAX_LEVELS + 4];   // entries appended per level (index 0 unused)
     uint32_t overflow;
     uint32_t pad[3];
-    unsigned long long shadow;
-    unsigned long long work[6];
+    unsigned long long shadow[RT_STAT_SHARDS];
+    unsigned long long work[12];
 };
 
-#define RT_MAX_PASSES 4096
+#define RT_MAX_PASSES 1024
 #define RT_PASS_SAMPLES (4u << 20)    // level-0 samples per pass
 #define RT_POOL_FACTOR 6u             // node pool = 6x the pass size when materials bounce (level 0 + 5x for deeper levels)
 #define RT_MAX_TIMED 2048
@@ -139,15 +140,27 @@ extern "C" int rt_scene_create(const rt_flat_scene* sc, int device, rt_scene** o
     auto fail = [&](int code) { bvh_free(&bvh); free_scene(s); return code; };
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { rt_set_error("hipStreamCreate failed"); return fail(RT_ERR_DEVICE); }
 
-    std::vector<uint4> objs(sc->n_objects);
+    std::vector<uint4> objs(size_t(sc->n_objects) * 2);
     for (uint32_t i = 0; i < sc->n_objects; ++i) {
-        objs[i] = make_uint4(uint32_t(sc->objects[i].type), sc->objects[i].index, sc->objects[i].material, 0);
-        const rt_material& m = sc->materials[sc->objects[i].material];
+        const rt_object& o = sc->objects[i];
+        float prm[4] = {0, 0, 0, 0}, inv_r = 0;
+        if (o.type == RT_OBJ_SPHERE) {
+            const rt_sphere& sp = sc->spheres[o.index];
+            prm[0] = sp.center[0]; prm[1] = sp.center[1]; prm[2] = sp.center[2]; prm[3] = sp.radius;
+            inv_r = float(1.0 / double(sp.radius));      // reference src/container.h:72-75 (Sphere::getNormal's n /= radius)
+        } else if (o.type == RT_OBJ_PLANE) {
+            const rt_plane& pl = sc->planes[o.index];
+            prm[0] = pl.a; prm[1] = pl.b; prm[2] = pl.c; prm[3] = pl.d;
+        }
+        uint32_t bits[5];
+        std::memcpy(bits, prm, sizeof prm);
+        std::memcpy(bits + 4, &inv_r, sizeof inv_r);
+        objs[2 * i] = make_uint4(uint32_t(o.type), o.index, o.material, bits[4]);
+        objs[2 * i + 1] = make_uint4(bits[0], bits[1], bits[2], bits[3]);
+        const rt_material& m = sc->materials[o.material];
         if (m.reflective || m.refractive) s->has_bounce = true;
     }
-    std::vector<float4> sph(sc->n_spheres), pl(sc->n_planes), li(size_t(sc->n_lights) * 2);
-    for (uint32_t i = 0; i < sc->n_spheres; ++i) sph[i] = make_float4(sc->spheres[i].center[0], sc->spheres[i].center[1], sc->spheres[i].center[2], sc->spheres[i].radius);
-    for (uint32_t i = 0; i < sc->n_planes; ++i) pl[i] = make_float4(sc->planes[i].a, sc->planes[i].b, sc->planes[i].c, sc->planes[i].d);
+    std::vector<float4> li(size_t(sc->n_lights) * 2);
     for (uint32_t i = 0; i < sc->n_lights; ++i) {
         li[2 * i] = make_float4(sc->lights[i].pos[0], sc->lights[i].pos[1], sc->lights[i].pos[2], 0);
         li[2 * i + 1] = make_float4(sc->lights[i].color[0], sc->lights[i].color[1], sc->lights[i].color[2], 0);
@@ -171,8 +184,6 @@ extern "C" int rt_scene_create(const rt_flat_scene* sc, int device, rt_scene** o
     s->d.n_objects = sc->n_objects;
     s->d.n_lights = sc->n_lights;
     if ((rc = upload(s, objs.data(), objs.size(), &s->d.objects)) != RT_OK) return fail(rc);
-    if ((rc = upload(s, sph.data(), sph.size(), &s->d.spheres)) != RT_OK) return fail(rc);
-    if ((rc = upload(s, pl.data(), pl.size(), &s->d.planes)) != RT_OK) return fail(rc);
     if ((rc = upload(s, models.data(), models.size(), &s->d.models)) != RT_OK) return fail(rc);
     if ((rc = upload(s, sc->materials, size_t(sc->n_materials), &s->d.materials)) != RT_OK) return fail(rc);
     if ((rc = upload(s, li.data(), li.size(), &s->d.lights)) != RT_OK) return fail(rc);
@@ -282,7 +293,7 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
         A.sample0 = (px0 + done) * spp;
         A.counters = pc->level;
         A.overflow = &pc->overflow;
-        A.shadow_count = &pc->shadow;
+        A.shadow_count = pc->shadow;
         A.work = pc->work;
         const int levels = s->has_bounce ? A.max_depth : 0;
         for (int lv = 0; lv <= levels; ++lv) {
@@ -333,6 +344,7 @@ static int render_frame(rt_scene* s, const rt_camera* cam, const rt_params* prm,
     B.max_depth = prm->max_depth;
     B.spp = spp;
     B.pool_cap = s->pool_cap;
+    if (const char* dbg = std::getenv("RT_DEBUG_SKIP")) B.pad = uint32_t(std::atoi(dbg));   // timing experiments only
     B.rays = s->rays; B.node_a = s->node_a; B.node_b = s->node_b;
     B.aa = s->d_aa;
     std::memcpy(B.background, prm->background, sizeof B.background);
@@ -383,10 +395,11 @@ static int render_frame(rt_scene* s, const rt_camera* cam, const rt_params* prm,
         for (const PassRec& r : final_recs) {
             const PassCounters& pc = s->h_counters[r.slot];
             // level 0: every valid sample is one trace() call; deeper levels: appended entries
-            stats->shadow_rays += pc.shadow;
+            for (int k = 0; k < RT_STAT_SHARDS; ++k) stats->shadow_rays += pc.shadow[k];
             for (int lv = 1; lv < RT_MAX_LEVELS; ++lv) stats->level_rays[lv] += pc.level[lv];
             w.nodes_visited += pc.work[0]; w.tris_tested += pc.work[1]; w.spheres_tested += pc.work[2]; w.planes_tested += pc.work[3];
             w.wave_node_steps += pc.work[4]; w.wave_tri_steps += pc.work[5];
+            for (int k = 0; k < 6; ++k) w.segment_cycles[k] += pc.work[6 + k];
         }
         s->last_work = w;
         stats->passes = uint32_t(final_recs.size());
@@ -590,7 +603,7 @@ static int trace_chunk(rt_scene* s, const rt_params* prm, const float* d_rays, u
     LevelArgs A;
     std::memset(&A, 0, sizeof A);
     A.n0 = n; A.max_depth = prm->max_depth; A.spp = 1;
-    A.counters = s->d_counters->level; A.overflow = &s->d_counters->overflow; A.shadow_count = &s->d_counters->shadow;
+    A.counters = s->d_counters->level; A.overflow = &s->d_counters->overflow; A.shadow_count = s->d_counters->shadow;
     A.work = s->d_counters->work;
     A.node_a = s->node_a; A.node_b = s->node_b; A.user_rays = d_rays;
     // pool entry i >= n0 keeps its ray at rays[2*(i-n0)]; the ray array holds pool_cap - ws_n0 entries, so with
@@ -614,11 +627,12 @@ static int trace_chunk(rt_scene* s, const rt_params* prm, const float* d_rays, u
     if (!*overflow && stats) {
         stats->level_rays[0] += n;
         for (int lv = 1; lv < RT_MAX_LEVELS; ++lv) stats->level_rays[lv] += pc.level[lv];
-        stats->shadow_rays += pc.shadow;
+        for (int k = 0; k < RT_STAT_SHARDS; ++k) stats->shadow_rays += pc.shadow[k];
         stats->passes += 1;
         s->last_work.nodes_visited += pc.work[0]; s->last_work.tris_tested += pc.work[1];
         s->last_work.spheres_tested += pc.work[2]; s->last_work.planes_tested += pc.work[3];
         s->last_work.wave_node_steps += pc.work[4]; s->last_work.wave_tri_steps += pc.work[5];
+        for (int k = 0; k < 6; ++k) s->last_work.segment_cycles[k] += pc.work[6 + k];
     }
     return RT_OK;
 }

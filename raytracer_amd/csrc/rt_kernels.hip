@@ -50,6 +50,26 @@ __device__ __forceinline__ V3 ld3(const float* p) { return mk(p[0], p[1], p[2]);
 __device__ __forceinline__ V3 f4xyz(float4 v) { return mk(v.x, v.y, v.z); }
 
 struct Ray { V3 o, d; };
+
+// Wave-uniform, read-only scene tables (object table, models, lights) are read through the constant address space:
+// the compiler may then use scalar loads (s_load_dwordx4/x8 into SGPRs) although the kernel also stores to global
+// memory; through a plain pointer it falls back to per-lane vector loads whose latency sits in every object test.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#define RT_CONSTANT __attribute__((address_space(4)))
+__device__ __forceinline__ u32x4 ldc4(const void* base, uint32_t i16) {
+    return *((const RT_CONSTANT u32x4*)(base) + i16);
+}
+__device__ __forceinline__ float4 as_f4(u32x4 v) {
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+struct ModelRef { uint32_t root; float4 bb; };   // what traversal needs of a DModel
+__device__ __forceinline__ ModelRef load_model(const DModel* models, uint32_t m) {
+    const u32x4 a = ldc4(models, 2 * m), b = ldc4(models, 2 * m + 1);   // {root, first, n, cx} {cy, cz, r, pad}
+    ModelRef r;
+    r.root = a.x;
+    r.bb = make_float4(__uint_as_float(a.w), __uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z));
+    return r;
+}
 __device__ __forceinline__ V3 ray_point(const Ray& r, float t) { return r.o + r.d * t; }   // container.h:255
 
 // ---------------------------------------------------------------------------------------------------------
@@ -76,7 +96,8 @@ __device__ __forceinline__ Ray cast_ray(const DCamera& c, const float* __restric
 // Analytic primitives
 // ---------------------------------------------------------------------------------------------------------
 // reference src/primitives.cpp:173-203. `dist` is in/out: left untouched when neither branch applies.
-__device__ __forceinline__ bool sphere_isect(float4 s, const Ray& ray, float& dist, V3& normal) {
+// inv_r = (float)(1.0 / (double)radius), the reciprocal Vec3::operator/= forms (container.h:72-75), taken once on the host.
+__device__ __forceinline__ bool sphere_isect(float4 s, float inv_r, const Ray& ray, float& dist, V3& normal) {
     const V3 c = f4xyz(s);
     const V3 temp = ray.o - c;
     const float val1 = dot(temp, ray.d);
@@ -89,15 +110,14 @@ __device__ __forceinline__ bool sphere_isect(float4 s, const Ray& ray, float& di
     if (dist1 < 0 || dist2 < 0) dist = max_std(dist1, dist2);
     else if (dist1 > 0 && dist2 > 0) dist = min_std(dist1, dist2);
     const V3 n = ray_point(ray, dist) - c;
-    const float inv = (float)(1.0 / (double)s.w);  // container.h:72-75
-    normal = n * inv;
+    normal = n * inv_r;
     return dist > RT_EPS;
 }
 // The gate of Model::intersect only needs the boolean.
 __device__ __forceinline__ bool sphere_gate(float4 s, const Ray& ray) {
     float d = 0;   // uninitialised in the reference (primitives.cpp:366); defined as 0
     V3 n;
-    return sphere_isect(s, ray, d, n);
+    return sphere_isect(s, 0.0f, ray, d, n);
 }
 // reference src/primitives.cpp:11-25
 __device__ __forceinline__ bool plane_isect(float4 p, const Ray& ray, float& dist, V3& normal) {
@@ -131,7 +151,10 @@ __device__ __forceinline__ bool tri_isect(V3 v0, V3 e1, V3 e2, const Ray& ray, f
 // ---------------------------------------------------------------------------------------------------------
 #define RT_STACK 32   // RT_BVH_MAX_DEPTH deferred children + the sentinel
 
-struct Work { uint32_t nodes, tris, spheres, planes, wave_nodes, wave_tris; };
+struct Work { uint32_t nodes, tris, spheres, planes, wave_nodes, wave_tris; unsigned long long seg[6]; };
+
+// cycle stamp for the COUNT (diagnostic) builds only; the product build executes none
+__device__ __forceinline__ unsigned long long stamp() { return __builtin_readcyclecounter(); }
 
 __device__ __forceinline__ uint32_t lane_id();
 // 1 on exactly one active lane of the wave: counts how often the WAVE executes a loop body (COUNT builds)
@@ -232,16 +255,20 @@ __device__ __forceinline__ bool bvh_traverse(const DScene& S, uint32_t root, con
 // Model::intersect (reference src/primitives.cpp:364-384): dist = FLT_MAX, bounding-sphere gate, closest face,
 // normal = (1-u-v)*n0 + u*n1 + v*n2 (primitives.cpp:80, not normalised).
 template <bool COUNT>
-__device__ __forceinline__ bool model_closest(const DScene& S, const DModel& m, const Ray& ray, float& dist, V3& normal,
+__device__ __forceinline__ bool model_closest(const DScene& S, const ModelRef& m, const Ray& ray, float& dist, V3& normal,
                                               uint32_t* stack, Work& wk) {
     dist = FLT_MAX;
-    if (m.bb_radius >= 0) {
+    if (m.bb.w >= 0) {
         if (COUNT) wk.spheres++;
-        if (!sphere_gate(make_float4(m.bb_center[0], m.bb_center[1], m.bb_center[2], m.bb_radius), ray)) return false;
+        if (!sphere_gate(m.bb, ray)) return false;
     }
     float t, u, v;
     uint32_t face;
-    if (!bvh_traverse<false, COUNT>(S, m.root, ray, FLT_MAX, t, u, v, face, stack, wk)) return false;
+    unsigned long long c0 = 0;
+    if (COUNT) c0 = stamp();
+    const bool got = bvh_traverse<false, COUNT>(S, m.root, ray, FLT_MAX, t, u, v, face, stack, wk);
+    if (COUNT) wk.seg[5] += stamp() - c0;
+    if (!got) return false;
     const float4* np = reinterpret_cast<const float4*>(S.normals + face);
     const V3 n0 = f4xyz(np[0]), n1 = f4xyz(np[1]), n2 = f4xyz(np[2]);
     dist = t;
@@ -249,42 +276,54 @@ __device__ __forceinline__ bool model_closest(const DScene& S, const DModel& m, 
     return true;   // every accepted face already satisfied dist > EPS
 }
 template <bool COUNT>
-__device__ __forceinline__ bool model_any(const DScene& S, const DModel& m, const Ray& ray, float tmax, uint32_t* stack,
+__device__ __forceinline__ bool model_any(const DScene& S, const ModelRef& m, const Ray& ray, float tmax, uint32_t* stack,
                                           Work& wk) {
-    if (m.bb_radius >= 0) {
+    if (m.bb.w >= 0) {
         if (COUNT) wk.spheres++;
-        if (!sphere_gate(make_float4(m.bb_center[0], m.bb_center[1], m.bb_center[2], m.bb_radius), ray)) return false;
+        if (!sphere_gate(m.bb, ray)) return false;
     }
     float t, u, v;
     uint32_t face;
-    return bvh_traverse<true, COUNT>(S, m.root, ray, tmax, t, u, v, face, stack, wk);
+    unsigned long long c0 = 0;
+    if (COUNT) c0 = stamp();
+    const bool got = bvh_traverse<true, COUNT>(S, m.root, ray, tmax, t, u, v, face, stack, wk);
+    if (COUNT) wk.seg[5] += stamp() - c0;
+    return got;
 }
 
 // Closest-hit loop of trace() (reference src/raytracer.cpp:292-300): objects in scene order, strict <.
 // The object table is read with wave-uniform indices (scalar loads); only the per-lane tests diverge.
+// Object table entry k = two uint4: {type, index, material, sphere 1/r bits} and the float4 parameters of a sphere
+// (cx cy cz r) or plane (a b c d). The index k is wave-uniform, so both come in by scalar loads; the next entry is
+// requested before the current one is worked on.
 template <bool COUNT>
 __device__ __forceinline__ int closest_hit(const DScene& S, const Ray& ray, float& dist, V3& hitNormal, float& tmpdist,
                                            uint32_t* stack, Work& wk) {
     dist = FLT_MAX;
     int cur = -1;
     V3 tmpnormal = mk(0, 0, 0);
+    if (S.n_objects == 0) return cur;
+    u32x4 ob = ldc4(S.objects, 0), pb = ldc4(S.objects, 1);
     for (uint32_t k = 0; k < S.n_objects; ++k) {
-        const uint4 ob = S.objects[k];
+        const uint32_t kn = k + 1 < S.n_objects ? k + 1 : k;
+        const u32x4 ob_n = ldc4(S.objects, 2 * kn), pb_n = ldc4(S.objects, 2 * kn + 1);
+        const float4 prm = as_f4(pb);
         bool hit;
         if (ob.x == RT_OBJ_SPHERE) {
             if (COUNT) wk.spheres++;
-            hit = sphere_isect(S.spheres[ob.y], ray, tmpdist, tmpnormal);
+            hit = sphere_isect(prm, __uint_as_float(ob.w), ray, tmpdist, tmpnormal);
         } else if (ob.x == RT_OBJ_PLANE) {
             if (COUNT) wk.planes++;
-            hit = plane_isect(S.planes[ob.y], ray, tmpdist, tmpnormal);
+            hit = plane_isect(prm, ray, tmpdist, tmpnormal);
         } else {
-            hit = model_closest<COUNT>(S, S.models[ob.y], ray, tmpdist, tmpnormal, stack, wk);
+            hit = model_closest<COUNT>(S, load_model(S.models, ob.y), ray, tmpdist, tmpnormal, stack, wk);
         }
         if (hit && tmpdist < dist) {
             dist = tmpdist;
             hitNormal = tmpnormal;
             cur = (int)k;
         }
+        ob = ob_n; pb = pb_n;
     }
     return cur;
 }
@@ -295,22 +334,27 @@ __device__ __forceinline__ bool occluded(const DScene& S, const Ray& ray, float 
                                          Work& wk) {
     V3 tmpnormal;
     bool in = false;
+    if (S.n_objects == 0) return in;
+    u32x4 ob = ldc4(S.objects, 0), pb = ldc4(S.objects, 1);
     for (uint32_t k = 0; k < S.n_objects; ++k) {
-        const uint4 ob = S.objects[k];
+        const uint32_t kn = k + 1 < S.n_objects ? k + 1 : k;
+        const u32x4 ob_n = ldc4(S.objects, 2 * kn), pb_n = ldc4(S.objects, 2 * kn + 1);
+        const float4 prm = as_f4(pb);
         if (!in) {
             if (ob.x == RT_OBJ_SPHERE) {
                 if (COUNT) wk.spheres++;
-                const bool hit = sphere_isect(S.spheres[ob.y], ray, tmpdist, tmpnormal);
+                const bool hit = sphere_isect(prm, __uint_as_float(ob.w), ray, tmpdist, tmpnormal);
                 in = hit && tmpdist < ldist;
             } else if (ob.x == RT_OBJ_PLANE) {
                 if (COUNT) wk.planes++;
-                const bool hit = plane_isect(S.planes[ob.y], ray, tmpdist, tmpnormal);
+                const bool hit = plane_isect(prm, ray, tmpdist, tmpnormal);
                 in = hit && tmpdist < ldist;
             } else {
-                in = model_any<COUNT>(S, S.models[ob.y], ray, ldist, stack, wk);
+                in = model_any<COUNT>(S, load_model(S.models, ob.y), ray, ldist, stack, wk);
                 if (!in) tmpdist = FLT_MAX;   // Model::intersect leaves FLT_MAX in dist on a miss (primitives.cpp:368)
             }
         }
+        ob = ob_n; pb = pb_n;
     }
     return in;
 }
@@ -320,6 +364,21 @@ __device__ __forceinline__ bool occluded(const DScene& S, const Ray& ray, float 
 // ---------------------------------------------------------------------------------------------------------
 #define NODE_FOLD 1u     // has at least one child ray: colour is finished by the fold pass
 #define NODE_VALID 2u
+
+// pow(cosAlpha, specRefExp) of trace() (reference src/raytracer.cpp:343), evaluated in double as there. For the
+// small whole exponents scene files use (8 in every shipped material) the power is formed by squaring: at most a few
+// double roundings (relative error < 1e-15), which the narrowing to float that follows absorbs except when the value
+// sits within that distance of a float rounding boundary (probability ~1e-8 per call; libm's and the device
+// library's pow differ from each other by as much). Other exponents go to the device pow.
+__device__ __forceinline__ double spec_pow(double x, float e) {
+    const int n = (int)e;
+    if ((float)n == e && n >= 0 && n <= 64) {
+        double r = 1.0, b = x;
+        for (int k = n; k; k >>= 1) { if (k & 1) r *= b; b *= b; }
+        return r;
+    }
+    return pow(x, (double)e);
+}
 
 // reference src/raytracer.cpp:399-406. refl/refr are the children's colours already scaled by kr / kt
 // (raytracer.cpp:387,395), zero when the child does not exist (raytracer.cpp:384,390).
@@ -349,6 +408,22 @@ __device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool want) {
     if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
     base = __shfl(base, leader);
     return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+// Both child kinds with ONE atomic per wave: reflection slots first, refraction slots behind them.
+__device__ __forceinline__ void wave_append2(uint32_t* counter, bool a, bool b, uint32_t& slot_a, uint32_t& slot_b) {
+    const unsigned long long ma = __ballot(a), mb = __ballot(b);
+    slot_a = slot_b = 0;
+    if ((ma | mb) == 0) return;
+    const uint32_t lane = lane_id();
+    const uint32_t na = (uint32_t)__popcll(ma);
+    const int leader = __ffsll((long long)(ma | mb)) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(counter, na + (uint32_t)__popcll(mb));
+    base = __shfl(base, leader);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    slot_a = base + (uint32_t)__popcll(ma & below);
+    slot_b = base + na + (uint32_t)__popcll(mb & below);
 }
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
@@ -401,7 +476,7 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_trace_level(DScene S, LevelArgs
     const uint32_t next_base = end;               // children of this level are appended behind it
     uint32_t* next_count = A.counters + (A.level + 1);
 
-    Work wk = {0, 0, 0, 0, 0, 0};
+    Work wk = {0, 0, 0, 0, 0, 0, {0, 0, 0, 0, 0, 0}};
     uint32_t n_shadow = 0;
 
     // Rays per wave. Level 0 and large levels fill all 64 lanes. A level with few rays (deep bounces) is spread over
@@ -417,6 +492,8 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_trace_level(DScene S, LevelArgs
     for (uint32_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
         const uint32_t i = begin + grp * R + threadIdx.x;
         const bool active = threadIdx.x < R && i < end;
+        unsigned long long c0 = 0, c1 = 0;
+        if (COUNT) c0 = stamp();
         Ray ray;
         ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 0);
         bool valid = active;
@@ -444,19 +521,23 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_trace_level(DScene S, LevelArgs
         if (valid) {
             float dist, tmpdist = 0;    // tmpdist: uninitialised in the reference (raytracer.cpp:285); defined as 0
             V3 hitNormal = mk(0, 0, 0);
-            const int cur = closest_hit<COUNT>(S, ray, dist, hitNormal, tmpdist, stack, wk);
+            if (COUNT) { c1 = stamp(); wk.seg[0] += c1 - c0; c0 = c1; }
+            int cur = -1;
+            if (!(A.pad & 2u)) cur = closest_hit<COUNT>(S, ray, dist, hitNormal, tmpdist, stack, wk);
+            if (A.pad & 4u) cur = -1;
+            if (COUNT) { c1 = stamp(); wk.seg[1] += c1 - c0; c0 = c1; }
             if (cur < 0) {
                 rec_a = make_float4(A.background[0], A.background[1], A.background[2], 0);   // raytracer.cpp:302-304
                 rec_b.w = NODE_VALID;
             } else {
-                const uint32_t mat_id = S.objects[cur].z;
+                const uint32_t mat_id = S.objects[2 * cur].z;
                 const rt_material m = S.materials[mat_id];
                 const float bias = 0.0001f;                                                  // raytracer.cpp:286
                 const V3 hitPt = ray_point(ray, dist);
                 V3 color = mk(0, 0, 0);
                 bool red = false;
                 for (uint32_t li = 0; li < S.n_lights && !red; ++li) {                       // raytracer.cpp:311-345
-                    const float4 lp = S.lights[2 * li], lc = S.lights[2 * li + 1];
+                    const float4 lp = as_f4(ldc4(S.lights, 2 * li)), lc = as_f4(ldc4(S.lights, 2 * li + 1));
                     V3 lv = f4xyz(lp) - hitPt;
                     const float ldist = length(lv);
                     lv = normalize(lv);
@@ -464,7 +545,10 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_trace_level(DScene S, LevelArgs
                     sr.o = hitPt + hitNormal * bias;
                     sr.d = lv;
                     ++n_shadow;
-                    if (occluded<COUNT>(S, sr, ldist, tmpdist, stack, wk)) continue;
+                    if (COUNT) { c1 = stamp(); wk.seg[3] += c1 - c0; c0 = c1; }
+                    const bool occ = (A.pad & 1u) ? false : occluded<COUNT>(S, sr, ldist, tmpdist, stack, wk);   // pad: timing experiments only
+                    if (COUNT) { c1 = stamp(); wk.seg[2] += c1 - c0; c0 = c1; }
+                    if (occ) continue;
                     if (isnan3(hitNormal)) { red = true; break; }                            // raytracer.cpp:330-332
                     const float cosPhi = max_std(dot(hitNormal, lv), 0.0f);
                     const float fd = cosPhi / (ldist * ldist);
@@ -472,7 +556,7 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_trace_level(DScene S, LevelArgs
                                        ((m.color[2] * lc.z) * m.kd) * fd);
                     const V3 reflectRay = (hitNormal * 2.0f) * dot(hitNormal, lv) - lv;
                     const float cosAlpha = max_std(dot(reflectRay, lv), 0.0f);
-                    const float fs = (float)(pow((double)cosAlpha, (double)m.specRefExp) / (double)(ldist * ldist));
+                    const float fs = (float)(spec_pow((double)cosAlpha, m.specRefExp) / (double)(ldist * ldist));
                     color = color + mk((lc.x * m.ks) * fs, (lc.y * m.ks) * fs, (lc.z * m.ks) * fs);
                 }
                 if (red) {
@@ -521,8 +605,9 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_trace_level(DScene S, LevelArgs
         }
 
         // append child rays to the next level: one atomic per wave and child kind
-        const uint32_t s1 = wave_append(next_count, want_refl);
-        const uint32_t s2 = wave_append(next_count, want_refr);
+        if (COUNT) { c1 = stamp(); wk.seg[3] += c1 - c0; c0 = c1; }
+        uint32_t s1, s2;
+        wave_append2(next_count, want_refl, want_refr, s1, s2);
         if (want_refl) {
             const uint64_t slot = (uint64_t)next_base + s1;
             if (slot < A.pool_cap) {
@@ -547,11 +632,12 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_trace_level(DScene S, LevelArgs
             A.node_a[i] = rec_a;
             A.node_b[i] = rec_b;
         }
+        if (COUNT) { c1 = stamp(); wk.seg[4] += c1 - c0; }
     }
 
     // statistics: one atomic per wave
     const uint32_t ns = wave_sum(n_shadow);
-    if (lane_id() == 0 && ns) atomicAdd(A.shadow_count, (unsigned long long)ns);
+    if (lane_id() == 0 && ns) atomicAdd(A.shadow_count + (blockIdx.x & (RT_STAT_SHARDS - 1)), (unsigned long long)ns);
     if (COUNT) {
         const uint32_t a = wave_sum(wk.nodes), b = wave_sum(wk.tris), c = wave_sum(wk.spheres), d = wave_sum(wk.planes);
         if (lane_id() == 0) {
@@ -560,6 +646,9 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_trace_level(DScene S, LevelArgs
             atomicAdd(A.work + 2, (unsigned long long)c);
             atomicAdd(A.work + 3, (unsigned long long)d);
         }
+        // per-lane cycle sums of the segments (lane 0 of each wave is representative: stamps are wave-uniform)
+        if (lane_id() == 0)
+            for (int k = 0; k < 6; ++k) atomicAdd(A.work + 6 + k, wk.seg[k]);
         const uint32_t e = wave_sum(wk.wave_nodes), f = wave_sum(wk.wave_tris);
         if (lane_id() == 0) {
             atomicAdd(A.work + 4, (unsigned long long)e);
@@ -668,16 +757,17 @@ __global__ __launch_bounds__(RT_BLOCK) void k_intersect(DScene S, int object, co
     if (i >= n) return;
     Ray ray;
     ray.o = ld3(rays + 6 * (size_t)i); ray.d = ld3(rays + 6 * (size_t)i + 3);
-    Work wk = {0, 0, 0, 0, 0, 0};
+    Work wk = {0, 0, 0, 0, 0, 0, {0, 0, 0, 0, 0, 0}};
     float d = 0;
     V3 nrm = mk(0, 0, 0);
     int hit = -1;
     if (object >= 0) {
-        const uint4 ob = S.objects[object];
+        const u32x4 ob = ldc4(S.objects, 2 * object), pb = ldc4(S.objects, 2 * object + 1);
+        const float4 prm = as_f4(pb);
         bool h;
-        if (ob.x == RT_OBJ_SPHERE) h = sphere_isect(S.spheres[ob.y], ray, d, nrm);
-        else if (ob.x == RT_OBJ_PLANE) h = plane_isect(S.planes[ob.y], ray, d, nrm);
-        else h = model_closest<false>(S, S.models[ob.y], ray, d, nrm, stack, wk);
+        if (ob.x == RT_OBJ_SPHERE) h = sphere_isect(prm, __uint_as_float(ob.w), ray, d, nrm);
+        else if (ob.x == RT_OBJ_PLANE) h = plane_isect(prm, ray, d, nrm);
+        else h = model_closest<false>(S, load_model(S.models, ob.y), ray, d, nrm, stack, wk);
         if (h) hit = object;
     } else {
         float tmp = 0;
@@ -696,7 +786,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_occluded(DScene S, const float* __
     if (i >= n) return;
     Ray ray;
     ray.o = ld3(rays + 6 * (size_t)i); ray.d = ld3(rays + 6 * (size_t)i + 3);
-    Work wk = {0, 0, 0, 0, 0, 0};
+    Work wk = {0, 0, 0, 0, 0, 0, {0, 0, 0, 0, 0, 0}};
     float tmp = 0;
     occ[i] = occluded<false>(S, ray, max_dist[i], tmp, stack, wk) ? 1 : 0;
 }

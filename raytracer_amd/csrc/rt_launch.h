@@ -7,14 +7,13 @@
 
 #define RT_BLOCK 64          // one wave per workgroup: waves retire independently, no barrier is ever needed
 #define RT_MAX_LEVELS 16     // recursion levels 0..max_depth, max_depth <= 15
+#define RT_STAT_SHARDS 256    // statistics atomics are spread over this many words: one word saturates at ~90 atomics/us
 
 // Scene in HBM (SoA). All pointers are device pointers owned by rt_scene.
 struct DScene {
-    const uint4* objects;        // (type, index, material, 0), scene order
+    const uint4* objects;        // 2 per object, scene order: {type, index, material, sphere 1/r bits}, {4 float params}
     uint32_t n_objects;
     uint32_t n_lights;
-    const float4* spheres;       // cx cy cz r
-    const float4* planes;        // a b c d
     const DModel* models;
     const rt_material* materials;
     const float4* lights;        // 2 per light: pos, color
@@ -54,7 +53,7 @@ struct LevelArgs {
     uint32_t pad;
     uint32_t* counters;          // [RT_MAX_LEVELS+1] entries appended per level (index 0 unused)
     uint32_t* overflow;          // set to 1 if a child did not fit
-    unsigned long long* shadow_count;
+    unsigned long long* shadow_count;   // [RT_STAT_SHARDS], indexed by workgroup
     unsigned long long* work;    // [4] nodes, tris, spheres, planes (COUNT builds only)
     float4* rays;                // 2 per pool entry >= n0: origin, direction
     float4* node_a;              // per pool entry: r g b rCoef
