@@ -129,9 +129,11 @@ typedef struct rt_stats {
     uint64_t level_rays[16];  /* trace() invocations per recursion level               */
     uint32_t passes;          /* image passes the frame was split into                 */
     uint32_t retries;         /* passes re-run with a smaller size after queue overflow */
-    float    kernel_ms;       /* HIP-event time of all kernels of this call            */
-    float    trace_kernel_ms; /* of which: the trace_level kernels                     */
-    uint32_t trace_launches;  /* number of trace_level launches                        */
+    float    kernel_ms;       /* HIP-event time of all kernels of this call (timed calls run on one stream) */
+    float    extend_ms;       /* of which: the closest-hit kernels (k_extend), summed over their launches   */
+    float    shade_ms;        /* of which: the light-loop kernels (k_shade)                                  */
+    uint32_t extend_launches;
+    uint32_t shade_launches;
     uint32_t reserved;
 } rt_stats;
 
@@ -213,7 +215,8 @@ typedef struct rt_bvh_info {
 int rt_scene_bvh_info(const rt_scene* scene, rt_bvh_info* out);
 
 /* Traversal work of the last call that passed a non-NULL stats AND had counting enabled with
- * rt_set_count_work(1): node visits / triangle tests / sphere / plane tests summed over all rays. */
+ * rt_set_count_work(1): node visits / triangle tests / sphere / plane tests summed over all rays, per kernel:
+ * rt_get_work(kernel = 0: closest-hit kernel k_extend, 1: light-loop kernel k_shade, -1: both). */
 typedef struct rt_work {
     uint64_t nodes_visited;
     uint64_t tris_tested;
@@ -221,11 +224,9 @@ typedef struct rt_work {
     uint64_t planes_tested;
     uint64_t wave_node_steps;   /* times a 64-lane wave executed the node step (any lane active) */
     uint64_t wave_tri_steps;    /* times a wave executed the triangle test                        */
-    uint64_t segment_cycles[6]; /* diagnostic: wave cycles in ray fetch, closest hit, shadow tests, shading,
-                                   append+write, and (inside the 2nd/3rd) BVH traversal           */
 } rt_work;
 int rt_set_count_work(rt_scene* scene, int enable);
-int rt_get_work(const rt_scene* scene, rt_work* out);
+int rt_get_work(const rt_scene* scene, int kernel, rt_work* out);
 
 const char* rt_last_error(void);   /* thread-local message of the last failing call */
 const char* rt_version(void);

@@ -70,8 +70,8 @@ class rt_params(C.Structure):
 class rt_stats(C.Structure):
     _fields_ = [("trace_calls", C.c_uint64), ("shadow_rays", C.c_uint64),
                 ("level_rays", C.c_uint64 * 16), ("passes", C.c_uint32), ("retries", C.c_uint32),
-                ("kernel_ms", C.c_float), ("trace_kernel_ms", C.c_float),
-                ("trace_launches", C.c_uint32), ("reserved", C.c_uint32)]
+                ("kernel_ms", C.c_float), ("extend_ms", C.c_float), ("shade_ms", C.c_float),
+                ("extend_launches", C.c_uint32), ("shade_launches", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class rt_bvh_info(C.Structure):
@@ -83,8 +83,7 @@ class rt_bvh_info(C.Structure):
 class rt_work(C.Structure):
     _fields_ = [("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64),
                 ("spheres_tested", C.c_uint64), ("planes_tested", C.c_uint64),
-                ("wave_node_steps", C.c_uint64), ("wave_tri_steps", C.c_uint64),
-                ("segment_cycles", C.c_uint64 * 6)]
+                ("wave_node_steps", C.c_uint64), ("wave_tri_steps", C.c_uint64)]
 
 
 def fptr(a):
@@ -143,7 +142,7 @@ def load(path=None):
     lib.rt_trace.argtypes = [vp, C.POINTER(rt_params), FP, u32, FP, C.POINTER(rt_stats)]
     lib.rt_scene_bvh_info.argtypes = [vp, C.POINTER(rt_bvh_info)]
     lib.rt_set_count_work.argtypes = [vp, C.c_int]
-    lib.rt_get_work.argtypes = [vp, C.POINTER(rt_work)]
+    lib.rt_get_work.argtypes = [vp, C.c_int, C.POINTER(rt_work)]
     lib.rt_last_error.restype = C.c_char_p
     lib.rt_version.restype = C.c_char_p
     if path is None:

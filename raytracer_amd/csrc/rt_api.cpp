@@ -43,6 +43,7 @@ void rt_set_error(const char* fmt, ...) {
 // ---------------------------------------------------------------------------------------------------------
 struct PassCounters {                 // one per pass, zeroed by one memset per frame
     uint32_t level[RT_MAX_LEVELS + 4];   // entries appended per level (index 0 unused)
+    uint32_t cancel[RT_MAX_LEVELS + 4];  // per level: children of parents that took trace()'s `return red` exit
     uint32_t overflow;
     uint32_t pad[3];
     unsigned long long shadow[RT_STAT_SHARDS];
@@ -53,11 +54,13 @@ struct PassCounters {                 // one per pass, zeroed by one memset per 
 #define RT_PASS_SAMPLES (4u << 20)    // level-0 samples per pass
 #define RT_POOL_FACTOR 6u             // node pool = 6x the pass size when materials bounce (level 0 + 5x for deeper levels)
 #define RT_MAX_TIMED 2048
-#define RT_LEVEL_GRID 4096u           // workgroups of a level >= 1 launch (grid-stride over the device-side count)
+#define RT_LEVEL_GRID 8192u           // workgroups of a level >= 1 launch (grid-stride over the device-side count)
 
 struct rt_scene {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t shade_stream = nullptr;   // k_shade runs here, next to k_extend of the deeper levels
+    hipEvent_t ev_sync[4] = {nullptr, nullptr, nullptr, nullptr};
     DScene d{};                        // device pointers
     std::vector<void*> owned;          // everything to hipFree
     uint32_t n_models = 0, n_faces = 0, n_nodes = 0, bvh_depth = 0;
@@ -68,6 +71,8 @@ struct rt_scene {
     float4* node_a = nullptr;
     uint4* node_b = nullptr;
     float4* rays = nullptr;
+    float4* hit_n = nullptr;
+    float4* hit_p = nullptr;
     PassCounters* d_counters = nullptr;
     PassCounters* h_counters = nullptr;   // pinned
     float* d_aa = nullptr;
@@ -75,7 +80,7 @@ struct rt_scene {
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     std::vector<hipEvent_t> ev_pool;
     bool count_work = false;
-    rt_work last_work{};
+    rt_work last_work[2]{};            // k_extend, k_shade
     int last_overflow = 0;
 };
 
@@ -83,11 +88,13 @@ static int free_scene(rt_scene* s) {
     if (!s) return RT_OK;
     hipSetDevice(s->device);
     for (void* p : s->owned) hipFree(p);
-    hipFree(s->node_a); hipFree(s->node_b); hipFree(s->rays); hipFree(s->d_counters); hipFree(s->d_aa); hipFree(s->d_frame);
+    hipFree(s->node_a); hipFree(s->node_b); hipFree(s->rays); hipFree(s->hit_n); hipFree(s->hit_p); hipFree(s->d_counters); hipFree(s->d_aa); hipFree(s->d_frame);
     if (s->h_counters) hipHostFree(s->h_counters);
     if (s->ev_begin) hipEventDestroy(s->ev_begin);
     if (s->ev_end) hipEventDestroy(s->ev_end);
     for (hipEvent_t e : s->ev_pool) hipEventDestroy(e);
+    for (hipEvent_t e : s->ev_sync) if (e) hipEventDestroy(e);
+    if (s->shade_stream) hipStreamDestroy(s->shade_stream);
     if (s->stream) hipStreamDestroy(s->stream);
     delete s;
     return RT_OK;
@@ -138,7 +145,10 @@ extern "C" int rt_scene_create(const rt_flat_scene* sc, int device, rt_scene** o
     rt_scene* s = new rt_scene();
     s->device = device;
     auto fail = [&](int code) { bvh_free(&bvh); free_scene(s); return code; };
-    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) { rt_set_error("hipStreamCreate failed"); return fail(RT_ERR_DEVICE); }
+    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&s->shade_stream, hipStreamNonBlocking) != hipSuccess) { rt_set_error("hipStreamCreate failed"); return fail(RT_ERR_DEVICE); }
+    for (hipEvent_t& e : s->ev_sync)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { rt_set_error("hipEventCreate failed"); return fail(RT_ERR_DEVICE); }
 
     std::vector<uint4> objs(size_t(sc->n_objects) * 2);
     for (uint32_t i = 0; i < sc->n_objects; ++i) {
@@ -223,9 +233,17 @@ extern "C" int rt_set_count_work(rt_scene* s, int enable) {
     s->count_work = enable != 0;
     return RT_OK;
 }
-extern "C" int rt_get_work(const rt_scene* s, rt_work* out) {
-    if (!s || !out) { rt_set_error("null argument"); return RT_ERR_INVALID; }
-    *out = s->last_work;
+static void add_work(rt_work& w, const unsigned long long* c) {
+    w.nodes_visited += c[0]; w.tris_tested += c[1]; w.spheres_tested += c[2]; w.planes_tested += c[3];
+    w.wave_node_steps += c[4]; w.wave_tri_steps += c[5];
+}
+extern "C" int rt_get_work(const rt_scene* s, int kernel, rt_work* out) {
+    if (!s || !out || kernel < -1 || kernel > 1) { rt_set_error("bad argument"); return RT_ERR_INVALID; }
+    if (kernel >= 0) { *out = s->last_work[kernel]; return RT_OK; }
+    const rt_work &a = s->last_work[0], &b = s->last_work[1];
+    out->nodes_visited = a.nodes_visited + b.nodes_visited; out->tris_tested = a.tris_tested + b.tris_tested;
+    out->spheres_tested = a.spheres_tested + b.spheres_tested; out->planes_tested = a.planes_tested + b.planes_tested;
+    out->wave_node_steps = a.wave_node_steps + b.wave_node_steps; out->wave_tri_steps = a.wave_tri_steps + b.wave_tri_steps;
     return RT_OK;
 }
 
@@ -234,12 +252,14 @@ extern "C" int rt_get_work(const rt_scene* s, rt_work* out) {
 // ---------------------------------------------------------------------------------------------------------
 static int ensure_workspace(rt_scene* s, uint32_t n0) {
     if (n0 <= s->ws_n0) return RT_OK;
-    hipFree(s->node_a); hipFree(s->node_b); hipFree(s->rays);
-    s->node_a = nullptr; s->node_b = nullptr; s->rays = nullptr; s->ws_n0 = 0; s->pool_cap = 0;
+    hipFree(s->node_a); hipFree(s->node_b); hipFree(s->rays); hipFree(s->hit_n); hipFree(s->hit_p);
+    s->node_a = nullptr; s->node_b = nullptr; s->rays = nullptr; s->hit_n = nullptr; s->hit_p = nullptr; s->ws_n0 = 0; s->pool_cap = 0;
     const uint64_t cap = uint64_t(n0) * (s->has_bounce ? RT_POOL_FACTOR : 1u);
     if (cap > 0xFFFFFFF0ull) { rt_set_error("pass too large"); return RT_ERR_LIMIT; }
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->node_a), cap * sizeof(float4)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->node_b), cap * sizeof(uint4)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->hit_n), cap * sizeof(float4)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->hit_p), cap * sizeof(float4)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->rays), std::max<uint64_t>(cap - n0, 1) * 2 * sizeof(float4)));
     s->ws_n0 = n0;
     s->pool_cap = uint32_t(cap);
@@ -271,13 +291,42 @@ struct FrameJob {
     hipStream_t st;
     LevelArgs base;          // everything that is constant over the frame
     uint8_t* d_out;
-    bool timed;
+    bool timed;              // per-launch events, everything on one stream
     uint32_t n_timed;
+    std::vector<uint8_t> timed_kind;   // 0 extend, 1 shade
     uint32_t n_pass_used;
 };
 
+// One kernel launch, bracketed by events when the frame is timed.
+template <typename F>
+static int timed_launch(FrameJob& J, hipStream_t st, uint8_t kind, F&& launch) {
+    rt_scene* s = J.s;
+    hipEvent_t e1 = nullptr;
+    if (J.timed && J.n_timed < RT_MAX_TIMED) {
+        while (s->ev_pool.size() < size_t(2 * (J.n_timed + 1))) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e));
+            s->ev_pool.push_back(e);
+        }
+        HIP_TRY(hipEventRecord(s->ev_pool[2 * J.n_timed], st));
+        e1 = s->ev_pool[2 * J.n_timed + 1];
+        J.timed_kind.push_back(kind);
+        ++J.n_timed;
+    }
+    launch();
+    if (e1) HIP_TRY(hipEventRecord(e1, st));
+    return RT_OK;
+}
+
 // Enqueue the passes covering pixels [px0, px0+npx) of the frame's pixel order, pass_px pixels at a time.
 // Records which PassCounters slot each pass used in `slots` (px0, npx, slot).
+//
+// Schedule of one pass with L bounce levels (E = k_extend, S = k_shade, F = k_fold):
+//   stream A (the caller's):  E0  E1  E2 ... EL                      | F(L-1) ... F1  resolve
+//   stream B (shade_stream):      S0  S1            S(2..L)          |
+// S never feeds E, so the level-to-level chain on A is one closest-hit traversal per level; the shadow traversals of
+// level k run next to the closest-hit traversals of the levels below it. A waits for B before folding. A timed frame
+// (stats requested) issues the same launches on ONE stream, so that each kernel's duration is its own.
 struct PassRec { uint64_t px0; uint32_t npx; uint32_t slot; };
 
 static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass_px, std::vector<PassRec>& recs) {
@@ -292,33 +341,40 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
         A.n0 = cnt * spp;
         A.sample0 = (px0 + done) * spp;
         A.counters = pc->level;
+        A.cancelled = pc->cancel;
         A.overflow = &pc->overflow;
         A.shadow_count = pc->shadow;
         A.work = pc->work;
         const int levels = s->has_bounce ? A.max_depth : 0;
-        for (int lv = 0; lv <= levels; ++lv) {
-            A.level = lv;
-            const uint32_t grid = lv == 0 ? (A.n0 + RT_BLOCK - 1) / RT_BLOCK : RT_LEVEL_GRID;
-            hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (J.timed && J.n_timed < RT_MAX_TIMED) {
-                while (s->ev_pool.size() < size_t(2 * (J.n_timed + 1))) {
-                    hipEvent_t e;
-                    HIP_TRY(hipEventCreate(&e));
-                    s->ev_pool.push_back(e);
-                }
-                e0 = s->ev_pool[2 * J.n_timed]; e1 = s->ev_pool[2 * J.n_timed + 1];
-                ++J.n_timed;
-                HIP_TRY(hipEventRecord(e0, J.st));
+        const bool overlap = !J.timed && levels >= 1;
+        hipStream_t sa = J.st, sb = overlap ? s->shade_stream : J.st;
+        const uint32_t grid0 = (A.n0 + RT_BLOCK - 1) / RT_BLOCK;
+        int rc;
+        auto shade = [&](int lo, int hi, int ev) -> int {
+            if (overlap) {
+                HIP_TRY(hipEventRecord(s->ev_sync[ev], sa));
+                HIP_TRY(hipStreamWaitEvent(sb, s->ev_sync[ev], 0));
             }
-            launch_trace_level(lv == 0 ? 0 : 1, s->count_work, s->d, A, grid, J.st);
-            if (e1) HIP_TRY(hipEventRecord(e1, J.st));
+            LevelArgs B = A;
+            B.level = lo; B.level_hi = hi;
+            return timed_launch(J, sb, 1, [&] { launch_shade(s->count_work, s->d, B, hi == 0 ? grid0 : RT_LEVEL_GRID, sb); });
+        };
+        for (int lv = 0; lv <= levels; ++lv) {
+            A.level = lv; A.level_hi = lv;
+            if ((rc = timed_launch(J, sa, 0, [&] { launch_extend(lv == 0 ? 0 : 1, s->count_work, s->d, A, lv == 0 ? grid0 : RT_LEVEL_GRID, sa); })) != RT_OK) return rc;
+            if (lv <= 1 && (rc = shade(lv, lv, lv)) != RT_OK) return rc;
+        }
+        if (levels >= 2 && (rc = shade(2, levels, 2)) != RT_OK) return rc;
+        if (overlap) {
+            HIP_TRY(hipEventRecord(s->ev_sync[3], sb));
+            HIP_TRY(hipStreamWaitEvent(sa, s->ev_sync[3], 0));
         }
         for (int lv = levels - 1; lv >= 1; --lv) {
-            A.level = lv;
-            launch_fold(s->d, A, 1024, J.st);
+            A.level = lv; A.level_hi = lv;
+            launch_fold(s->d, A, 1024, sa);
         }
-        A.level = 0;
-        launch_resolve(s->d, A, J.d_out, J.st);
+        A.level = 0; A.level_hi = 0;
+        launch_resolve(s->d, A, J.d_out, sa);
         HIP_TRY(hipGetLastError());
         recs.push_back({px0 + done, cnt, slot});
     }
@@ -344,8 +400,8 @@ static int render_frame(rt_scene* s, const rt_camera* cam, const rt_params* prm,
     B.max_depth = prm->max_depth;
     B.spp = spp;
     B.pool_cap = s->pool_cap;
-    if (const char* dbg = std::getenv("RT_DEBUG_SKIP")) B.pad = uint32_t(std::atoi(dbg));   // timing experiments only
-    B.rays = s->rays; B.node_a = s->node_a; B.node_b = s->node_b;
+    if (const char* dbg = std::getenv("RT_DEBUG_SKIP")) B.debug = uint32_t(std::atoi(dbg));   // timing experiments only
+    B.rays = s->rays; B.node_a = s->node_a; B.node_b = s->node_b; B.hit_n = s->hit_n; B.hit_p = s->hit_p;
     B.aa = s->d_aa;
     std::memcpy(B.background, prm->background, sizeof B.background);
     B.pm = pm;
@@ -391,30 +447,26 @@ static int render_frame(rt_scene* s, const rt_camera* cam, const rt_params* prm,
     if (stats) {
         HIP_TRY(hipEventRecord(s->ev_end, st));
         HIP_TRY(hipStreamSynchronize(st));
-        rt_work w{};
+        rt_work w[2]{};
         for (const PassRec& r : final_recs) {
             const PassCounters& pc = s->h_counters[r.slot];
             // level 0: every valid sample is one trace() call; deeper levels: appended entries
             for (int k = 0; k < RT_STAT_SHARDS; ++k) stats->shadow_rays += pc.shadow[k];
-            for (int lv = 1; lv < RT_MAX_LEVELS; ++lv) stats->level_rays[lv] += pc.level[lv];
-            w.nodes_visited += pc.work[0]; w.tris_tested += pc.work[1]; w.spheres_tested += pc.work[2]; w.planes_tested += pc.work[3];
-            w.wave_node_steps += pc.work[4]; w.wave_tri_steps += pc.work[5];
-            for (int k = 0; k < 6; ++k) w.segment_cycles[k] += pc.work[6 + k];
+            for (int lv = 1; lv < RT_MAX_LEVELS; ++lv) stats->level_rays[lv] += pc.level[lv] - pc.cancel[lv];
+            add_work(w[0], pc.work); add_work(w[1], pc.work + 6);
         }
-        s->last_work = w;
+        s->last_work[0] = w[0]; s->last_work[1] = w[1];
         stats->passes = uint32_t(final_recs.size());
         stats->retries = retries;
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, s->ev_begin, s->ev_end));
         stats->kernel_ms = ms;
-        float tms = 0;
         for (uint32_t i = 0; i < J.n_timed; ++i) {
             float t = 0;
             HIP_TRY(hipEventElapsedTime(&t, s->ev_pool[2 * i], s->ev_pool[2 * i + 1]));
-            tms += t;
+            if (J.timed_kind[i] == 0) { stats->extend_ms += t; stats->extend_launches += 1; }
+            else { stats->shade_ms += t; stats->shade_launches += 1; }
         }
-        stats->trace_kernel_ms = tms;
-        stats->trace_launches = J.n_timed;
     }
     return RT_OK;
 }
@@ -603,9 +655,10 @@ static int trace_chunk(rt_scene* s, const rt_params* prm, const float* d_rays, u
     LevelArgs A;
     std::memset(&A, 0, sizeof A);
     A.n0 = n; A.max_depth = prm->max_depth; A.spp = 1;
-    A.counters = s->d_counters->level; A.overflow = &s->d_counters->overflow; A.shadow_count = s->d_counters->shadow;
+    A.counters = s->d_counters->level; A.cancelled = s->d_counters->cancel; A.overflow = &s->d_counters->overflow;
+    A.shadow_count = s->d_counters->shadow;
     A.work = s->d_counters->work;
-    A.node_a = s->node_a; A.node_b = s->node_b; A.user_rays = d_rays;
+    A.node_a = s->node_a; A.node_b = s->node_b; A.hit_n = s->hit_n; A.hit_p = s->hit_p; A.user_rays = d_rays;
     // pool entry i >= n0 keeps its ray at rays[2*(i-n0)]; the ray array holds pool_cap - ws_n0 entries, so with
     // n0 = n <= ws_n0 the usable pool shrinks accordingly
     A.rays = s->rays;
@@ -613,11 +666,13 @@ static int trace_chunk(rt_scene* s, const rt_params* prm, const float* d_rays, u
     std::memcpy(A.background, prm->background, sizeof A.background);
     const int levels = s->has_bounce ? A.max_depth : 0;
     for (int lv = 0; lv <= levels; ++lv) {
-        A.level = lv;
-        launch_trace_level(lv == 0 ? 2 : 1, s->count_work, s->d, A, lv == 0 ? (n + RT_BLOCK - 1) / RT_BLOCK : RT_LEVEL_GRID, st);
+        A.level = lv; A.level_hi = lv;
+        launch_extend(lv == 0 ? 2 : 1, s->count_work, s->d, A, lv == 0 ? (n + RT_BLOCK - 1) / RT_BLOCK : RT_LEVEL_GRID, st);
     }
-    for (int lv = levels - 1; lv >= 1; --lv) { A.level = lv; launch_fold(s->d, A, 1024, st); }
-    A.level = 0;
+    A.level = 0; A.level_hi = levels;          // one shade launch over the hits of all levels
+    launch_shade(s->count_work, s->d, A, std::max<uint32_t>((n + RT_BLOCK - 1) / RT_BLOCK, levels ? RT_LEVEL_GRID : 1u), st);
+    for (int lv = levels - 1; lv >= 1; --lv) { A.level = lv; A.level_hi = lv; launch_fold(s->d, A, 1024, st); }
+    A.level = 0; A.level_hi = 0;
     launch_resolve_rgb(s->d, A, d_rgb, st);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(s->h_counters, s->d_counters, sizeof(PassCounters), hipMemcpyDeviceToHost, st));
@@ -626,13 +681,10 @@ static int trace_chunk(rt_scene* s, const rt_params* prm, const float* d_rays, u
     *overflow = pc.overflow != 0;
     if (!*overflow && stats) {
         stats->level_rays[0] += n;
-        for (int lv = 1; lv < RT_MAX_LEVELS; ++lv) stats->level_rays[lv] += pc.level[lv];
+        for (int lv = 1; lv < RT_MAX_LEVELS; ++lv) stats->level_rays[lv] += pc.level[lv] - pc.cancel[lv];
         for (int k = 0; k < RT_STAT_SHARDS; ++k) stats->shadow_rays += pc.shadow[k];
         stats->passes += 1;
-        s->last_work.nodes_visited += pc.work[0]; s->last_work.tris_tested += pc.work[1];
-        s->last_work.spheres_tested += pc.work[2]; s->last_work.planes_tested += pc.work[3];
-        s->last_work.wave_node_steps += pc.work[4]; s->last_work.wave_tri_steps += pc.work[5];
-        for (int k = 0; k < 6; ++k) s->last_work.segment_cycles[k] += pc.work[6 + k];
+        add_work(s->last_work[0], pc.work); add_work(s->last_work[1], pc.work + 6);
     }
     return RT_OK;
 }
@@ -649,7 +701,7 @@ extern "C" int rt_trace(rt_scene* s, const rt_params* prm, const float* rays, ui
     DevBuf dr, dout;
     if (dr.alloc(sizeof(float) * 6 * size_t(n)) || dout.alloc(sizeof(float) * 3 * size_t(n))) { rt_set_error("hipMalloc failed"); return RT_ERR_DEVICE; }
     HIP_TRY(hipMemcpy(dr.p, rays, sizeof(float) * 6 * size_t(n), hipMemcpyHostToDevice));
-    s->last_work = rt_work{};
+    s->last_work[0] = rt_work{}; s->last_work[1] = rt_work{};
     for (uint32_t done = 0; done < n;) {
         const uint32_t cnt = std::min(chunk, n - done);
         bool overflow = false;

@@ -145,16 +145,26 @@ __device__ __forceinline__ bool tri_isect(V3 v0, V3 e1, V3 e2, const Ray& ray, f
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// BVH traversal. One lane = one ray; the stack of deferred children lives in LDS, one column per lane
-// (entry [level][lane]: conflict-free, lanes of a wave hit distinct banks). Depth <= RT_BVH_MAX_DEPTH by
-// construction (bvh_build.cpp), so 32 entries can never overflow.
+// BVH traversal. One lane = one ray. The stack of deferred children is split: the first RT_STACK_LDS entries live in
+// LDS, one column per lane (entry [level][lane]: conflict-free, lanes of a wave hit distinct banks); deeper entries
+// go to a private (scratch) array that is touched only by rays that get that deep. 20 LDS entries = 5 KB per wave,
+// so LDS never caps occupancy (160 KB / 32 waves per CU). Depth <= RT_BVH_MAX_DEPTH by construction (bvh_build.cpp).
 // ---------------------------------------------------------------------------------------------------------
-#define RT_STACK 32   // RT_BVH_MAX_DEPTH deferred children + the sentinel
+#define RT_STACK_LDS 20
+#define RT_STACK_SPILL (RT_BVH_MAX_DEPTH + 2 - RT_STACK_LDS)
 
-struct Work { uint32_t nodes, tris, spheres, planes, wave_nodes, wave_tris; unsigned long long seg[6]; };
+struct Stack {
+    uint32_t* lds;                      // this lane's column
+    uint32_t spill[RT_STACK_SPILL];
+    __device__ __forceinline__ void put(int sp, uint32_t v) {
+        if (sp < RT_STACK_LDS) lds[sp * RT_BLOCK] = v; else spill[sp - RT_STACK_LDS] = v;
+    }
+    __device__ __forceinline__ uint32_t get(int sp) const {
+        return sp < RT_STACK_LDS ? lds[sp * RT_BLOCK] : spill[sp - RT_STACK_LDS];
+    }
+};
 
-// cycle stamp for the COUNT (diagnostic) builds only; the product build executes none
-__device__ __forceinline__ unsigned long long stamp() { return __builtin_readcyclecounter(); }
+struct Work { uint32_t nodes, tris, spheres, planes, wave_nodes, wave_tris; };
 
 __device__ __forceinline__ uint32_t lane_id();
 // 1 on exactly one active lane of the wave: counts how often the WAVE executes a loop body (COUNT builds)
@@ -191,7 +201,7 @@ __device__ __forceinline__ float safe_rcp(float d) {
 // executed back to back for disjoint lane sets in every iteration.
 template <bool ANY, bool COUNT>
 __device__ __forceinline__ bool bvh_traverse(const DScene& S, uint32_t root, const Ray& ray, float tmax, float& best_t,
-                                             float& best_u, float& best_v, uint32_t& best_face, uint32_t* stack,
+                                             float& best_u, float& best_v, uint32_t& best_face, Stack& stack,
                                              Work& wk) {
     // culling direction: a zero (or denormal) component is replaced by +-1e-30 so that lo*inv - o*inv keeps the sign of
     // lo - o instead of becoming inf - inf; only the box tests use it, the triangle test gets the ray as it is
@@ -202,7 +212,7 @@ __device__ __forceinline__ bool bvh_traverse(const DScene& S, uint32_t root, con
     bool found = false;
     uint32_t face = 0xFFFFFFFFu;
     float bu = 0, bv = 0;
-    stack[0] = RT_DONE;
+    stack.put(0, RT_DONE);
     int sp = 1;
     uint32_t cur = root;       // RT_NO_CHILD == RT_DONE for an empty model
     while (cur != RT_DONE) {
@@ -216,21 +226,21 @@ __device__ __forceinline__ bool bvh_traverse(const DScene& S, uint32_t root, con
             const float t1 = slab(b.z, b.w, c.x, c.y, c.z, c.w, inv, ood, tcull, h1);
             if (h0 && h1) {
                 const bool first0 = t0 <= t1;
-                stack[sp * RT_BLOCK] = first0 ? r.y : r.x;
+                stack.put(sp, first0 ? r.y : r.x);
                 ++sp;
                 cur = first0 ? r.x : r.y;
             } else if (h0 || h1) {
                 cur = h0 ? r.x : r.y;
             } else {
                 --sp;
-                cur = stack[sp * RT_BLOCK];
+                cur = stack.get(sp);
             }
         }
         if (cur != RT_DONE) {
             const uint32_t start = cur & RT_LEAF_START_MASK;
             const uint32_t cnt = ((cur >> 27) & 15u) + 1u;
             --sp;
-            cur = stack[sp * RT_BLOCK];
+            cur = stack.get(sp);
             for (uint32_t i = 0; i < cnt; ++i) {
                 const float4* tp = reinterpret_cast<const float4*>(S.tris + (start + i));
                 const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
@@ -256,7 +266,7 @@ __device__ __forceinline__ bool bvh_traverse(const DScene& S, uint32_t root, con
 // normal = (1-u-v)*n0 + u*n1 + v*n2 (primitives.cpp:80, not normalised).
 template <bool COUNT>
 __device__ __forceinline__ bool model_closest(const DScene& S, const ModelRef& m, const Ray& ray, float& dist, V3& normal,
-                                              uint32_t* stack, Work& wk) {
+                                              Stack& stack, Work& wk) {
     dist = FLT_MAX;
     if (m.bb.w >= 0) {
         if (COUNT) wk.spheres++;
@@ -264,10 +274,7 @@ __device__ __forceinline__ bool model_closest(const DScene& S, const ModelRef& m
     }
     float t, u, v;
     uint32_t face;
-    unsigned long long c0 = 0;
-    if (COUNT) c0 = stamp();
     const bool got = bvh_traverse<false, COUNT>(S, m.root, ray, FLT_MAX, t, u, v, face, stack, wk);
-    if (COUNT) wk.seg[5] += stamp() - c0;
     if (!got) return false;
     const float4* np = reinterpret_cast<const float4*>(S.normals + face);
     const V3 n0 = f4xyz(np[0]), n1 = f4xyz(np[1]), n2 = f4xyz(np[2]);
@@ -276,7 +283,7 @@ __device__ __forceinline__ bool model_closest(const DScene& S, const ModelRef& m
     return true;   // every accepted face already satisfied dist > EPS
 }
 template <bool COUNT>
-__device__ __forceinline__ bool model_any(const DScene& S, const ModelRef& m, const Ray& ray, float tmax, uint32_t* stack,
+__device__ __forceinline__ bool model_any(const DScene& S, const ModelRef& m, const Ray& ray, float tmax, Stack& stack,
                                           Work& wk) {
     if (m.bb.w >= 0) {
         if (COUNT) wk.spheres++;
@@ -284,10 +291,7 @@ __device__ __forceinline__ bool model_any(const DScene& S, const ModelRef& m, co
     }
     float t, u, v;
     uint32_t face;
-    unsigned long long c0 = 0;
-    if (COUNT) c0 = stamp();
     const bool got = bvh_traverse<true, COUNT>(S, m.root, ray, tmax, t, u, v, face, stack, wk);
-    if (COUNT) wk.seg[5] += stamp() - c0;
     return got;
 }
 
@@ -298,9 +302,10 @@ __device__ __forceinline__ bool model_any(const DScene& S, const ModelRef& m, co
 // requested before the current one is worked on.
 template <bool COUNT>
 __device__ __forceinline__ int closest_hit(const DScene& S, const Ray& ray, float& dist, V3& hitNormal, float& tmpdist,
-                                           uint32_t* stack, Work& wk) {
+                                           uint32_t& material, Stack& stack, Work& wk) {
     dist = FLT_MAX;
     int cur = -1;
+    material = 0;
     V3 tmpnormal = mk(0, 0, 0);
     if (S.n_objects == 0) return cur;
     u32x4 ob = ldc4(S.objects, 0), pb = ldc4(S.objects, 1);
@@ -322,6 +327,7 @@ __device__ __forceinline__ int closest_hit(const DScene& S, const Ray& ray, floa
             dist = tmpdist;
             hitNormal = tmpnormal;
             cur = (int)k;
+            material = ob.z;
         }
         ob = ob_n; pb = pb_n;
     }
@@ -330,7 +336,7 @@ __device__ __forceinline__ int closest_hit(const DScene& S, const Ray& ray, floa
 
 // Shadow loop of trace() (reference src/raytracer.cpp:319-325): any object with hit && tmpdist < ldist.
 template <bool COUNT>
-__device__ __forceinline__ bool occluded(const DScene& S, const Ray& ray, float ldist, float& tmpdist, uint32_t* stack,
+__device__ __forceinline__ bool occluded(const DScene& S, const Ray& ray, float ldist, float& tmpdist, Stack& stack,
                                          Work& wk) {
     V3 tmpnormal;
     bool in = false;
@@ -454,46 +460,73 @@ __device__ __forceinline__ bool map_pixel(const PixelMap& pm, uint64_t q, uint32
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// k_trace_level: one recursion level of trace() for all rays of that level.
+// One recursion level of trace() is two kernels:
+//   k_extend  closest hit of every ray of the level (raytracer.cpp:292-308), Fresnel term and the child rays
+//             (raytracer.cpp:347-396) appended to level+1. Needs ~half the registers of a fused kernel.
+//   k_shade   the light loop (raytracer.cpp:311-345) for the hits of one or several levels. Nothing downstream of
+//             k_extend waits for it, so the host runs it on a second stream, next to k_extend of the deeper levels:
+//             the dependent chain of a level is ONE traversal instead of 1 + n_lights.
+// The `return red` exit (raytracer.cpp:330-332) is decided by k_shade, after the children were appended: a hit with a
+// NaN normal has at most one child, the reflection ray, whose direction is all NaN; such a ray misses every primitive
+// (all comparisons false) and shoots no shadow rays, so it costs one wasted background node. k_shade then clears
+// the parent's NODE_FOLD flag (the child is ignored) and counts the child in `cancelled` so that the ray statistics
+// equal the reference's.
 //   SRC 0: level 0, rays generated from the camera     SRC 1: level >= 1, rays read from the pool
 //   SRC 2: level 0, rays supplied by the caller (rt_trace)
 // ---------------------------------------------------------------------------------------------------------
-template <int SRC, bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK, 4) void k_trace_level(DScene S, LevelArgs A) {
-    __shared__ uint32_t lds_stack[RT_STACK * RT_BLOCK];
-    uint32_t* stack = lds_stack + threadIdx.x;
+#define NODE_HIT 4u      // has a hit record: k_shade computes its colour
 
-    // level range inside the pool: [begin, end)
-    uint32_t begin = 0, end = A.n0;
-    if (SRC == 1) {
-        uint64_t e = A.n0;
-        for (int i = 1; i < A.level; ++i) e += A.counters[i];
-        // 64-bit sums: after an overflow the counters hold the ATTEMPTED appends (flagged by the producing level)
-        const uint64_t b64 = e, e64 = e + A.counters[A.level];
-        begin = (uint32_t)(b64 < A.pool_cap ? b64 : A.pool_cap);
-        end = (uint32_t)(e64 < A.pool_cap ? e64 : A.pool_cap);
+// Pool range [begin, end) of levels lo..hi (level 0 = [0, n0), level k >= 1 behind level k-1). 64-bit sums: after an
+// overflow the counters hold the ATTEMPTED appends (flagged by the producing level).
+__device__ __forceinline__ void level_range(const LevelArgs& A, int lo, int hi, uint32_t& begin, uint32_t& end) {
+    uint64_t b = 0, e = A.n0;
+    for (int l = 1; l <= hi; ++l) {
+        if (l == lo) b = e;
+        e += A.counters[l];
     }
+    begin = (uint32_t)(b < A.pool_cap ? b : A.pool_cap);
+    end = (uint32_t)(e < A.pool_cap ? e : A.pool_cap);
+}
+
+// Rays per wave. Level 0 and large levels fill all 64 lanes. A range with few rays (deep bounces) is spread over the
+// whole grid instead, R rays per wave: its rays are incoherent, so a wave's time is close to the SUM of its lanes'
+// paths, and fewer lanes per wave shorten the critical path at no cost in total issue slots.
+__device__ __forceinline__ uint32_t rays_per_wave(uint32_t n_items) {
+    const uint32_t per = (n_items + gridDim.x - 1) / gridDim.x;
+    return per < 1u ? 1u : (per < RT_BLOCK ? per : RT_BLOCK);
+}
+
+__device__ __forceinline__ void flush_work(unsigned long long* out, const Work& wk) {
+    const uint32_t a = wave_sum(wk.nodes), b = wave_sum(wk.tris), c = wave_sum(wk.spheres), d = wave_sum(wk.planes);
+    const uint32_t e = wave_sum(wk.wave_nodes), f = wave_sum(wk.wave_tris);
+    if (lane_id() == 0) {
+        atomicAdd(out + 0, (unsigned long long)a);
+        atomicAdd(out + 1, (unsigned long long)b);
+        atomicAdd(out + 2, (unsigned long long)c);
+        atomicAdd(out + 3, (unsigned long long)d);
+        atomicAdd(out + 4, (unsigned long long)e);
+        atomicAdd(out + 5, (unsigned long long)f);
+    }
+}
+
+template <int SRC, bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) void k_extend(DScene S, LevelArgs A) {
+    __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
+    Stack stack;
+    stack.lds = lds_stack + threadIdx.x;
+
+    uint32_t begin = 0, end = A.n0;
+    if (SRC == 1) level_range(A, A.level, A.level, begin, end);
     const uint32_t next_base = end;               // children of this level are appended behind it
     uint32_t* next_count = A.counters + (A.level + 1);
+    Work wk = {0, 0, 0, 0, 0, 0};
 
-    Work wk = {0, 0, 0, 0, 0, 0, {0, 0, 0, 0, 0, 0}};
-    uint32_t n_shadow = 0;
-
-    // Rays per wave. Level 0 and large levels fill all 64 lanes. A level with few rays (deep bounces) is spread over
-    // the whole grid instead, R rays per wave: its rays are incoherent, so a wave's time is close to the SUM of its
-    // lanes' paths, and fewer lanes per wave shorten the level's critical path at no cost in total issue slots.
-    uint32_t R = RT_BLOCK;
-    if (SRC == 1) {
-        const uint32_t per = (end - begin + gridDim.x - 1) / gridDim.x;
-        R = per < 1u ? 1u : (per < RT_BLOCK ? per : RT_BLOCK);
-    }
     const uint32_t n_items = end - begin;
+    const uint32_t R = SRC == 1 ? rays_per_wave(n_items) : RT_BLOCK;
     const uint32_t n_groups = (n_items + R - 1) / R;
     for (uint32_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
         const uint32_t i = begin + grp * R + threadIdx.x;
         const bool active = threadIdx.x < R && i < end;
-        unsigned long long c0 = 0, c1 = 0;
-        if (COUNT) c0 = stamp();
         Ray ray;
         ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 0);
         bool valid = active;
@@ -512,100 +545,60 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_trace_level(DScene S, LevelArgs
             }
         }
 
-        float4 rec_a = make_float4(0, 0, 0, 0);
         uint4 rec_b = make_uint4(RT_NO_CHILD, RT_NO_CHILD, 0, 0);
         bool want_refl = false, want_refr = false;
         Ray r_refl, r_refr;
         r_refl.o = r_refl.d = r_refr.o = r_refr.d = mk(0, 0, 0);
+        V3 hitNormal = mk(0, 0, 0), hitPt = mk(0, 0, 0);
+        float tmpdist = 0, rCoef = 0;     // tmpdist: uninitialised in the reference (raytracer.cpp:285); defined as 0
 
         if (valid) {
-            float dist, tmpdist = 0;    // tmpdist: uninitialised in the reference (raytracer.cpp:285); defined as 0
-            V3 hitNormal = mk(0, 0, 0);
-            if (COUNT) { c1 = stamp(); wk.seg[0] += c1 - c0; c0 = c1; }
+            float dist;
+            uint32_t mat_id;
             int cur = -1;
-            if (!(A.pad & 2u)) cur = closest_hit<COUNT>(S, ray, dist, hitNormal, tmpdist, stack, wk);
-            if (A.pad & 4u) cur = -1;
-            if (COUNT) { c1 = stamp(); wk.seg[1] += c1 - c0; c0 = c1; }
-            if (cur < 0) {
-                rec_a = make_float4(A.background[0], A.background[1], A.background[2], 0);   // raytracer.cpp:302-304
-                rec_b.w = NODE_VALID;
-            } else {
-                const uint32_t mat_id = S.objects[2 * cur].z;
-                const rt_material m = S.materials[mat_id];
+            if (!(A.debug & 2u)) cur = closest_hit<COUNT>(S, ray, dist, hitNormal, tmpdist, mat_id, stack, wk);
+            if (A.debug & 4u) cur = -1;
+            rec_b.w = NODE_VALID;
+            if (cur >= 0) {
+                const rt_material* mp = S.materials + mat_id;
+                const float refractiveIdx = mp->refractiveIdx;
+                const bool reflective = mp->reflective != 0, refractive = mp->refractive != 0;
                 const float bias = 0.0001f;                                                  // raytracer.cpp:286
-                const V3 hitPt = ray_point(ray, dist);
-                V3 color = mk(0, 0, 0);
-                bool red = false;
-                for (uint32_t li = 0; li < S.n_lights && !red; ++li) {                       // raytracer.cpp:311-345
-                    const float4 lp = as_f4(ldc4(S.lights, 2 * li)), lc = as_f4(ldc4(S.lights, 2 * li + 1));
-                    V3 lv = f4xyz(lp) - hitPt;
-                    const float ldist = length(lv);
-                    lv = normalize(lv);
-                    Ray sr;
-                    sr.o = hitPt + hitNormal * bias;
-                    sr.d = lv;
-                    ++n_shadow;
-                    if (COUNT) { c1 = stamp(); wk.seg[3] += c1 - c0; c0 = c1; }
-                    const bool occ = (A.pad & 1u) ? false : occluded<COUNT>(S, sr, ldist, tmpdist, stack, wk);   // pad: timing experiments only
-                    if (COUNT) { c1 = stamp(); wk.seg[2] += c1 - c0; c0 = c1; }
-                    if (occ) continue;
-                    if (isnan3(hitNormal)) { red = true; break; }                            // raytracer.cpp:330-332
-                    const float cosPhi = max_std(dot(hitNormal, lv), 0.0f);
-                    const float fd = cosPhi / (ldist * ldist);
-                    color = color + mk(((m.color[0] * lc.x) * m.kd) * fd, ((m.color[1] * lc.y) * m.kd) * fd,
-                                       ((m.color[2] * lc.z) * m.kd) * fd);
-                    const V3 reflectRay = (hitNormal * 2.0f) * dot(hitNormal, lv) - lv;
-                    const float cosAlpha = max_std(dot(reflectRay, lv), 0.0f);
-                    const float fs = (float)(spec_pow((double)cosAlpha, m.specRefExp) / (double)(ldist * ldist));
-                    color = color + mk((lc.x * m.ks) * fs, (lc.y * m.ks) * fs, (lc.z * m.ks) * fs);
-                }
-                if (red) {
-                    rec_a = make_float4(1, 0, 0, 0);
-                    rec_b.w = NODE_VALID;
-                } else {
-                    const int depth = A.level + 1;                                           // raytracer.cpp:347
-                    V3 refractNormal = hitNormal;
-                    float cosI = 0, cosT = 0, sinSqrPhit = 0, n1 = 0, n2 = 0, n = 0, rCoef = 0;
-                    if (m.refractive && depth <= A.max_depth) {                              // raytracer.cpp:357-381
-                        cosI = dot(ray.d, hitNormal);
-                        if (cosI < 0.0f) { n1 = 1.0f; n2 = m.refractiveIdx; cosI = -cosI; }
-                        else { n1 = m.refractiveIdx; n2 = 1.0f; refractNormal = neg(refractNormal); }
-                        n = n1 / n2;
-                        sinSqrPhit = n * n * (1 - cosI * cosI);
-                        if (sinSqrPhit <= 1) {
-                            cosT = sqrtf(1 - sinSqrPhit);
-                            const float Rorth = (n1 * cosI - n2 * cosT) / (n1 * cosI + n2 * cosT);
-                            const float Rpar = (n2 * cosI - n1 * cosT) / (n2 * cosI + n1 * cosT);
-                            rCoef = (Rorth * Rorth + Rpar * Rpar) / 2;
-                        } else {
-                            rCoef = 1;
-                        }
-                    }
-                    if (m.reflective && depth <= A.max_depth) {                              // raytracer.cpp:385-388
-                        want_refl = true;
-                        r_refl.d = (neg(hitNormal) * 2.0f) * dot(hitNormal, ray.d) + ray.d;
-                        r_refl.o = hitPt + hitNormal * bias;
-                    }
-                    if (m.refractive && depth <= A.max_depth && sinSqrPhit <= 1) {           // raytracer.cpp:391-396
-                        want_refr = true;
-                        r_refr.d = ray.d * n + refractNormal * (n * cosI - cosT);
-                        r_refr.o = hitPt - refractNormal * bias;
-                    }
-                    rec_b.z = mat_id;
-                    if (want_refl || want_refr) {
-                        rec_a = make_float4(color.x, color.y, color.z, rCoef);
-                        rec_b.w = NODE_VALID | NODE_FOLD;
+                hitPt = ray_point(ray, dist);
+                const int depth = A.level + 1;                                               // raytracer.cpp:347
+                V3 refractNormal = hitNormal;
+                float cosI = 0, cosT = 0, sinSqrPhit = 0, n1 = 0, n2 = 0, n = 0;
+                if (refractive && depth <= A.max_depth) {                                    // raytracer.cpp:357-381
+                    cosI = dot(ray.d, hitNormal);
+                    if (cosI < 0.0f) { n1 = 1.0f; n2 = refractiveIdx; cosI = -cosI; }
+                    else { n1 = refractiveIdx; n2 = 1.0f; refractNormal = neg(refractNormal); }
+                    n = n1 / n2;
+                    sinSqrPhit = n * n * (1 - cosI * cosI);
+                    if (sinSqrPhit <= 1) {
+                        cosT = sqrtf(1 - sinSqrPhit);
+                        const float Rorth = (n1 * cosI - n2 * cosT) / (n1 * cosI + n2 * cosT);
+                        const float Rpar = (n2 * cosI - n1 * cosT) / (n2 * cosI + n1 * cosT);
+                        rCoef = (Rorth * Rorth + Rpar * Rpar) / 2;
                     } else {
-                        const V3 c = finish_color(color, m, rCoef, mk(0, 0, 0), mk(0, 0, 0));
-                        rec_a = make_float4(c.x, c.y, c.z, rCoef);
-                        rec_b.w = NODE_VALID;
+                        rCoef = 1;
                     }
                 }
+                if (reflective && depth <= A.max_depth) {                                    // raytracer.cpp:385-388
+                    want_refl = true;
+                    r_refl.d = (neg(hitNormal) * 2.0f) * dot(hitNormal, ray.d) + ray.d;
+                    r_refl.o = hitPt + hitNormal * bias;
+                }
+                if (refractive && depth <= A.max_depth && sinSqrPhit <= 1) {                 // raytracer.cpp:391-396
+                    want_refr = true;
+                    r_refr.d = ray.d * n + refractNormal * (n * cosI - cosT);
+                    r_refr.o = hitPt - refractNormal * bias;
+                }
+                rec_b.z = mat_id;
+                rec_b.w = NODE_VALID | NODE_HIT | ((want_refl || want_refr) ? NODE_FOLD : 0u);
             }
         }
 
-        // append child rays to the next level: one atomic per wave and child kind
-        if (COUNT) { c1 = stamp(); wk.seg[3] += c1 - c0; c0 = c1; }
+        // append child rays to the next level: one atomic per wave
         uint32_t s1, s2;
         wave_append2(next_count, want_refl, want_refr, s1, s2);
         if (want_refl) {
@@ -629,32 +622,91 @@ __global__ __launch_bounds__(RT_BLOCK, 4) void k_trace_level(DScene S, LevelArgs
             }
         }
         if (active) {
-            A.node_a[i] = rec_a;
             A.node_b[i] = rec_b;
+            if (rec_b.w & NODE_HIT) {
+                A.hit_n[i] = make_float4(hitNormal.x, hitNormal.y, hitNormal.z, tmpdist);
+                A.hit_p[i] = make_float4(hitPt.x, hitPt.y, hitPt.z, rCoef);
+            } else if (rec_b.w & NODE_VALID) {
+                A.node_a[i] = make_float4(A.background[0], A.background[1], A.background[2], 0);   // raytracer.cpp:302-304
+            } else {
+                A.node_a[i] = make_float4(0, 0, 0, 0);
+            }
         }
-        if (COUNT) { c1 = stamp(); wk.seg[4] += c1 - c0; }
+    }
+    if (COUNT) flush_work(A.work, wk);
+}
+
+// Light loop of trace() (reference src/raytracer.cpp:311-345) for the hits of levels A.level..A.level_hi.
+template <bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) void k_shade(DScene S, LevelArgs A) {
+    __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
+    Stack stack;
+    stack.lds = lds_stack + threadIdx.x;
+
+    uint32_t begin = 0, end = A.n0;
+    if (A.level_hi > 0) level_range(A, A.level, A.level_hi, begin, end);
+    Work wk = {0, 0, 0, 0, 0, 0};
+    uint32_t n_shadow = 0;
+
+    const uint32_t n_items = end - begin;
+    const uint32_t R = A.level_hi > 0 ? rays_per_wave(n_items) : RT_BLOCK;
+    const uint32_t n_groups = (n_items + R - 1) / R;
+    for (uint32_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const uint32_t i = begin + grp * R + threadIdx.x;
+        const bool active = threadIdx.x < R && i < end;
+        uint4 b = make_uint4(0, 0, 0, 0);
+        if (active) b = A.node_b[i];
+        if (!(b.w & NODE_HIT)) continue;
+        const float4 hn = A.hit_n[i], hp = A.hit_p[i];
+        const V3 hitNormal = f4xyz(hn), hitPt = f4xyz(hp);
+        float tmpdist = hn.w;
+        const float rCoef = hp.w;
+        const rt_material m = S.materials[b.z];
+        const float bias = 0.0001f;                                                          // raytracer.cpp:286
+        V3 color = mk(0, 0, 0);
+        bool red = false;
+        for (uint32_t li = 0; li < S.n_lights && !red; ++li) {                               // raytracer.cpp:311-345
+            const float4 lp = as_f4(ldc4(S.lights, 2 * li)), lc = as_f4(ldc4(S.lights, 2 * li + 1));
+            V3 lv = f4xyz(lp) - hitPt;
+            const float ldist = length(lv);
+            lv = normalize(lv);
+            Ray sr;
+            sr.o = hitPt + hitNormal * bias;
+            sr.d = lv;
+            ++n_shadow;
+            const bool occ = (A.debug & 1u) ? false : occluded<COUNT>(S, sr, ldist, tmpdist, stack, wk);
+            if (occ) continue;
+            if (isnan3(hitNormal)) { red = true; break; }                                    // raytracer.cpp:330-332
+            const float cosPhi = max_std(dot(hitNormal, lv), 0.0f);
+            const float fd = cosPhi / (ldist * ldist);
+            color = color + mk(((m.color[0] * lc.x) * m.kd) * fd, ((m.color[1] * lc.y) * m.kd) * fd,
+                               ((m.color[2] * lc.z) * m.kd) * fd);
+            const V3 reflectRay = (hitNormal * 2.0f) * dot(hitNormal, lv) - lv;
+            const float cosAlpha = max_std(dot(reflectRay, lv), 0.0f);
+            const float fs = (float)(spec_pow((double)cosAlpha, m.specRefExp) / (double)(ldist * ldist));
+            color = color + mk((lc.x * m.ks) * fs, (lc.y * m.ks) * fs, (lc.z * m.ks) * fs);
+        }
+        if (red) {
+            A.node_a[i] = make_float4(1, 0, 0, 0);
+            if (b.w & NODE_FOLD) {      // children were appended speculatively: ignore them, and un-count them
+                A.node_b[i].w = NODE_VALID;
+                uint32_t lo = 0, hi = 0;
+                int lv = A.level;
+                for (; lv <= A.level_hi; ++lv) { level_range(A, lv, lv, lo, hi); if (i < hi) break; }
+                atomicAdd(A.cancelled + lv + 1, (b.x != RT_NO_CHILD ? 1u : 0u) + (b.y != RT_NO_CHILD ? 1u : 0u));
+            }
+        } else if (b.w & NODE_FOLD) {
+            A.node_a[i] = make_float4(color.x, color.y, color.z, rCoef);
+        } else {
+            const V3 c = finish_color(color, m, rCoef, mk(0, 0, 0), mk(0, 0, 0));
+            A.node_a[i] = make_float4(c.x, c.y, c.z, rCoef);
+        }
     }
 
-    // statistics: one atomic per wave
+    // statistics: one atomic per wave, spread over RT_STAT_SHARDS words
     const uint32_t ns = wave_sum(n_shadow);
     if (lane_id() == 0 && ns) atomicAdd(A.shadow_count + (blockIdx.x & (RT_STAT_SHARDS - 1)), (unsigned long long)ns);
-    if (COUNT) {
-        const uint32_t a = wave_sum(wk.nodes), b = wave_sum(wk.tris), c = wave_sum(wk.spheres), d = wave_sum(wk.planes);
-        if (lane_id() == 0) {
-            atomicAdd(A.work + 0, (unsigned long long)a);
-            atomicAdd(A.work + 1, (unsigned long long)b);
-            atomicAdd(A.work + 2, (unsigned long long)c);
-            atomicAdd(A.work + 3, (unsigned long long)d);
-        }
-        // per-lane cycle sums of the segments (lane 0 of each wave is representative: stamps are wave-uniform)
-        if (lane_id() == 0)
-            for (int k = 0; k < 6; ++k) atomicAdd(A.work + 6 + k, wk.seg[k]);
-        const uint32_t e = wave_sum(wk.wave_nodes), f = wave_sum(wk.wave_tris);
-        if (lane_id() == 0) {
-            atomicAdd(A.work + 4, (unsigned long long)e);
-            atomicAdd(A.work + 5, (unsigned long long)f);
-        }
-    }
+    if (COUNT) flush_work(A.work + 6, wk);
 }
 
 // Colour of pool node i once its children (one level deeper) are final.
@@ -672,11 +724,8 @@ __device__ __forceinline__ V3 node_color(const DScene& S, const float4* __restri
 
 // Fold of one level (>= 1): finishes every node whose children were traced one level deeper.
 __global__ __launch_bounds__(256) void k_fold(DScene S, LevelArgs A) {
-    uint64_t e = A.n0;
-    for (int i = 1; i < A.level; ++i) e += A.counters[i];
-    const uint64_t e64 = e + A.counters[A.level];
-    const uint32_t begin = (uint32_t)(e < A.pool_cap ? e : A.pool_cap);
-    const uint32_t end = (uint32_t)(e64 < A.pool_cap ? e64 : A.pool_cap);
+    uint32_t begin, end;
+    level_range(A, A.level, A.level, begin, end);
     for (uint32_t i = begin + blockIdx.x * 256 + threadIdx.x; i < end; i += gridDim.x * 256) {
         const uint4 b = A.node_b[i];
         if (b.w & NODE_FOLD) {
@@ -751,13 +800,14 @@ __global__ __launch_bounds__(RT_BLOCK) void k_cast_rays(DCamera cam, const float
 __global__ __launch_bounds__(RT_BLOCK) void k_intersect(DScene S, int object, const float* __restrict__ rays, uint32_t n,
                                                         int32_t* __restrict__ hit_obj, float* __restrict__ dist_out,
                                                         float* __restrict__ normal_out) {
-    __shared__ uint32_t lds_stack[RT_STACK * RT_BLOCK];
-    uint32_t* stack = lds_stack + threadIdx.x;
+    __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
+    Stack stack;
+    stack.lds = lds_stack + threadIdx.x;
     const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
     if (i >= n) return;
     Ray ray;
     ray.o = ld3(rays + 6 * (size_t)i); ray.d = ld3(rays + 6 * (size_t)i + 3);
-    Work wk = {0, 0, 0, 0, 0, 0, {0, 0, 0, 0, 0, 0}};
+    Work wk = {0, 0, 0, 0, 0, 0};
     float d = 0;
     V3 nrm = mk(0, 0, 0);
     int hit = -1;
@@ -771,7 +821,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_intersect(DScene S, int object, co
         if (h) hit = object;
     } else {
         float tmp = 0;
-        hit = closest_hit<false>(S, ray, d, nrm, tmp, stack, wk);
+        uint32_t mat;
+        hit = closest_hit<false>(S, ray, d, nrm, tmp, mat, stack, wk);
     }
     hit_obj[i] = hit;
     dist_out[i] = d;
@@ -780,13 +831,14 @@ __global__ __launch_bounds__(RT_BLOCK) void k_intersect(DScene S, int object, co
 
 __global__ __launch_bounds__(RT_BLOCK) void k_occluded(DScene S, const float* __restrict__ rays, const float* __restrict__ max_dist,
                                                        uint32_t n, uint8_t* __restrict__ occ) {
-    __shared__ uint32_t lds_stack[RT_STACK * RT_BLOCK];
-    uint32_t* stack = lds_stack + threadIdx.x;
+    __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
+    Stack stack;
+    stack.lds = lds_stack + threadIdx.x;
     const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
     if (i >= n) return;
     Ray ray;
     ray.o = ld3(rays + 6 * (size_t)i); ray.d = ld3(rays + 6 * (size_t)i + 3);
-    Work wk = {0, 0, 0, 0, 0, 0, {0, 0, 0, 0, 0, 0}};
+    Work wk = {0, 0, 0, 0, 0, 0};
     float tmp = 0;
     occ[i] = occluded<false>(S, ray, max_dist[i], tmp, stack, wk) ? 1 : 0;
 }
@@ -796,18 +848,23 @@ __global__ __launch_bounds__(RT_BLOCK) void k_occluded(DScene S, const float* __
 // ---------------------------------------------------------------------------------------------------------
 extern "C++" {
 
-void launch_trace_level(int src, bool count, const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st) {
+void launch_extend(int src, bool count, const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st) {
     dim3 g(grid), b(RT_BLOCK);
     if (src == 0) {
-        if (count) hipLaunchKernelGGL((k_trace_level<0, true>), g, b, 0, st, S, A);
-        else hipLaunchKernelGGL((k_trace_level<0, false>), g, b, 0, st, S, A);
+        if (count) hipLaunchKernelGGL((k_extend<0, true>), g, b, 0, st, S, A);
+        else hipLaunchKernelGGL((k_extend<0, false>), g, b, 0, st, S, A);
     } else if (src == 1) {
-        if (count) hipLaunchKernelGGL((k_trace_level<1, true>), g, b, 0, st, S, A);
-        else hipLaunchKernelGGL((k_trace_level<1, false>), g, b, 0, st, S, A);
+        if (count) hipLaunchKernelGGL((k_extend<1, true>), g, b, 0, st, S, A);
+        else hipLaunchKernelGGL((k_extend<1, false>), g, b, 0, st, S, A);
     } else {
-        if (count) hipLaunchKernelGGL((k_trace_level<2, true>), g, b, 0, st, S, A);
-        else hipLaunchKernelGGL((k_trace_level<2, false>), g, b, 0, st, S, A);
+        if (count) hipLaunchKernelGGL((k_extend<2, true>), g, b, 0, st, S, A);
+        else hipLaunchKernelGGL((k_extend<2, false>), g, b, 0, st, S, A);
     }
+}
+void launch_shade(bool count, const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st) {
+    dim3 g(grid), b(RT_BLOCK);
+    if (count) hipLaunchKernelGGL((k_shade<true>), g, b, 0, st, S, A);
+    else hipLaunchKernelGGL((k_shade<false>), g, b, 0, st, S, A);
 }
 void launch_fold(const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st) {
     hipLaunchKernelGGL(k_fold, dim3(grid), dim3(256), 0, st, S, A);

@@ -43,25 +43,32 @@ struct PixelMap {
     uint32_t pad;
 };
 
+// Pool entry i = one trace() invocation ("node"). Entries [0, n0) are level 0; level k >= 1 follows level k-1.
+//   k_extend writes  node_b (children, material, flags), hit_n, hit_p for a hit; node_a for a miss
+//   k_shade  writes  node_a for a hit (light loop of trace()), may downgrade node_b.w (the `return red` exit)
+//   k_fold / k_resolve read node_a / node_b
 struct LevelArgs {
     uint32_t n0;                 // level-0 samples of this pass (multiple of spp)
-    int32_t level;
+    int32_t level;               // k_extend / k_fold: the level; k_shade: first level of the range
+    int32_t level_hi;            // k_shade: last level of the range (inclusive)
     int32_t max_depth;
     uint32_t spp;
-    uint64_t sample0;            // first sample of the pass in the frame's sample order
     uint32_t pool_cap;           // node pool entries (all levels)
-    uint32_t pad;
+    uint64_t sample0;            // first sample of the pass in the frame's sample order
     uint32_t* counters;          // [RT_MAX_LEVELS+1] entries appended per level (index 0 unused)
+    uint32_t* cancelled;         // [RT_MAX_LEVELS+1] per level: speculative children whose parent took the red exit
     uint32_t* overflow;          // set to 1 if a child did not fit
     unsigned long long* shadow_count;   // [RT_STAT_SHARDS], indexed by workgroup
-    unsigned long long* work;    // [4] nodes, tris, spheres, planes (COUNT builds only)
+    unsigned long long* work;    // [6] lane nodes, tris, spheres, planes, wave node steps, wave tri steps (COUNT builds)
     float4* rays;                // 2 per pool entry >= n0: origin, direction
     float4* node_a;              // per pool entry: r g b rCoef
     uint4* node_b;               // per pool entry: refl child, refr child, material, flags
+    float4* hit_n;               // per pool entry with a hit: hitNormal xyz, tmpdist as the closest-hit loop left it
+    float4* hit_p;               // per pool entry with a hit: hitPt xyz, rCoef
     const float* aa;             // anti-aliasing pattern (device)
     const float* user_rays;      // SRC 2
     float background[3];
-    float pad2;
+    uint32_t debug;              // timing experiments only (RT_DEBUG_SKIP)
     PixelMap pm;
     DCamera cam;
 };
@@ -71,7 +78,8 @@ struct UntileArgs {
     uint32_t part_stride;   // tile slots between parts; 0 = packed
 };
 
-void launch_trace_level(int src, bool count, const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st);
+void launch_extend(int src, bool count, const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st);
+void launch_shade(bool count, const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st);
 void launch_fold(const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st);
 void launch_resolve(const DScene& S, const LevelArgs& A, uint8_t* out, hipStream_t st);
 void launch_resolve_rgb(const DScene& S, const LevelArgs& A, float* rgb, hipStream_t st);

@@ -358,9 +358,10 @@ class DeviceScene:
     def set_count_work(self, on):
         cabi.check(self.lib, self.lib.rt_set_count_work(self.h, int(on)))
 
-    def get_work(self):
+    def get_work(self, kernel=-1):
+        """Traversal work counters of the last counted call: kernel 0 = k_extend, 1 = k_shade, -1 = both."""
         w = cabi.rt_work()
-        cabi.check(self.lib, self.lib.rt_get_work(self.h, C.byref(w)))
+        cabi.check(self.lib, self.lib.rt_get_work(self.h, int(kernel), C.byref(w)))
         return w
 
 
