@@ -28,10 +28,11 @@ VALU_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: FP32 vector peak
 
 
 def algorithmic_work(work, rays, closest_rays, n_lights):
-    """SURVEY.md 8(d): bytes/ray = 64 N_node + 48 N_tri + 16 N_sphere + 16 N_plane + 48;
-    flops/ray = 48 N_node + 47 N_tri + 35 N_sphere + 13 N_plane + S (S = 17 + 60 per light for closest-hit rays)."""
-    b = 64 * work.nodes_visited + 48 * work.tris_tested + 16 * work.spheres_tested + 16 * work.planes_tested + 48 * rays
-    f = (48 * work.nodes_visited + 47 * work.tris_tested + 35 * work.spheres_tested + 13 * work.planes_tested
+    """bytes/ray = B_node N_node + 48 N_tri + 16 N_sphere + 16 N_plane + 48 with B_node = 128 (one
+    4-wide node = 4 child boxes, i.e. two of the survey's 64-B two-box nodes);
+    flops/ray = 96 N_node + 47 N_tri + 35 N_sphere + 13 N_plane + S (S = 17 + 60 per light for closest-hit rays)."""
+    b = 128 * work.nodes_visited + 48 * work.tris_tested + 16 * work.spheres_tested + 16 * work.planes_tested + 48 * rays
+    f = (96 * work.nodes_visited + 47 * work.tris_tested + 35 * work.spheres_tested + 13 * work.planes_tested
          + closest_rays * (17 + 60 * n_lights))
     return b, f
 

@@ -224,6 +224,12 @@ typedef struct rt_work {
     uint64_t planes_tested;
     uint64_t wave_node_steps;   /* times a 64-lane wave executed the node step (any lane active) */
     uint64_t wave_tri_steps;    /* times a wave executed the triangle test                        */
+    uint64_t trav_ticks_sum;    /* 10-ns ticks waves spent inside mesh traversal, summed over waves */
+    uint64_t trav_ticks_max;    /* ... the largest single wave                                     */
+    uint64_t batches;           /* 16-ray traversal batches                                        */
+    uint64_t trav_waves;        /* waves that ran at least one batch                               */
+    uint64_t wave_ticks_sum;    /* 10-ns ticks between a wave's start and its end, summed          */
+    uint64_t wave_ticks_max;    /* ... the longest-lived wave                                      */
 } rt_work;
 int rt_set_count_work(rt_scene* scene, int enable);
 int rt_get_work(const rt_scene* scene, int kernel, rt_work* out);

@@ -83,7 +83,9 @@ class rt_bvh_info(C.Structure):
 class rt_work(C.Structure):
     _fields_ = [("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64),
                 ("spheres_tested", C.c_uint64), ("planes_tested", C.c_uint64),
-                ("wave_node_steps", C.c_uint64), ("wave_tri_steps", C.c_uint64)]
+                ("wave_node_steps", C.c_uint64), ("wave_tri_steps", C.c_uint64),
+                ("trav_ticks_sum", C.c_uint64), ("trav_ticks_max", C.c_uint64), ("batches", C.c_uint64),
+                ("trav_waves", C.c_uint64), ("wave_ticks_sum", C.c_uint64), ("wave_ticks_max", C.c_uint64)]
 
 
 def fptr(a):

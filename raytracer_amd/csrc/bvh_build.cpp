@@ -1,4 +1,5 @@
-// bvh_build.cpp — host BVH builder (binned SAH) for the Model objects of a flat scene.
+// bvh_build.cpp — host BVH builder for the Model objects of a flat scene: binned-SAH binary tree, then collapsed to
+// the 4-children-per-node layout the quad traversal uses (rt_device.h).
 //
 // Replaces the reference's O(#faces) loop in Model::intersect (reference src/primitives.cpp:376-382) with a
 // hierarchy the GPU can cull with; the reference has no acceleration structure (its bounding-sphere gate,
@@ -35,9 +36,12 @@ struct Builder {
     std::vector<Box> tri_box;        // per original face
     std::vector<float> centroid;     // 3 per face
     std::vector<uint32_t> order;     // permutation of faces, leaf order at the end
-    BvhNode* nodes;
-    std::atomic<uint32_t> n_nodes{0};
-    std::atomic<uint32_t> max_depth{0};
+    struct Node2 { Box box[2]; uint32_t child[2]; };   // binary build tree: unpadded child boxes
+    std::vector<Node2> nodes2;
+    std::atomic<uint32_t> n_nodes2{0};
+    bool balanced = false;           // median splits only (fallback when the SAH tree needs too much stack)
+    Bvh4Node* nodes = nullptr;       // output
+    uint32_t n_nodes = 0;
 
     static constexpr int NBINS = 16;
 
@@ -60,19 +64,15 @@ struct Builder {
     uint32_t build(uint32_t b, uint32_t e, uint32_t depth, Box& bx) {
         const uint32_t n = e - b;
         bx = range_box(b, e);
-        if (n <= RT_MAX_LEAF_TRIS) {
-            uint32_t d = max_depth.load();
-            while (depth > d && !max_depth.compare_exchange_weak(d, depth)) {}
-            return RT_LEAF_BIT | ((n - 1) << 27) | b;
-        }
+        if (n <= RT_MAX_LEAF_TRIS) return RT_LEAF_BIT | ((n - 1) << 27) | b;
         // depth guard: once a balanced split is the only way to stay within RT_BVH_MAX_DEPTH, use it
         uint32_t need = 0;
         while ((uint64_t(RT_MAX_LEAF_TRIS) << need) < n) ++need;
         uint32_t mid = 0;
-        if (depth + need + 1 < RT_BVH_MAX_DEPTH) mid = sah_split(b, e, bx);
+        if (!balanced && depth + need + 1 < RT_BVH2_MAX_DEPTH) mid = sah_split(b, e, bx);
         if (mid <= b || mid >= e) mid = median_split(b, e, bx);
 
-        const uint32_t idx = n_nodes.fetch_add(1);
+        const uint32_t idx = n_nodes2.fetch_add(1);
         Box lb, rb;
         uint32_t lc, rc;
         if (n > 100000) {
@@ -85,12 +85,62 @@ struct Builder {
             lc = build(b, mid, depth + 1, lb);
             rc = build(mid, e, depth + 1, rb);
         }
-        BvhNode& nd = nodes[idx];
-        pad(lb, nd.lo0, nd.hi0);
-        pad(rb, nd.lo1, nd.hi1);
-        nd.child0 = lc;
-        nd.child1 = rc;
-        nd.pad0 = nd.pad1 = 0;
+        Node2& nd = nodes2[idx];
+        nd.box[0] = lb; nd.box[1] = rb;
+        nd.child[0] = lc; nd.child[1] = rc;
+        return idx;
+    }
+
+    // Collapse the binary subtree under interior node `n2` into 4-wide nodes. Children are gathered by opening,
+    // while fewer than 4 are held, the interior child with the largest surface (by_area) or simply both children of
+    // the node (level pairs: exactly two binary levels per 4-wide level, used with the balanced fallback tree).
+    // Returns the new node's index; depth = interior nodes on the longest path below and including it; stack = the
+    // most entries a traversal below it can have pending (k-1 siblings at every level it descends through).
+    uint32_t collapse(uint32_t n2, bool by_area, uint32_t& depth, uint32_t& stack) {
+        Box cb[4];
+        uint32_t cr[4];
+        int k = 2;
+        cb[0] = nodes2[n2].box[0]; cb[1] = nodes2[n2].box[1];
+        cr[0] = nodes2[n2].child[0]; cr[1] = nodes2[n2].child[1];
+        if (by_area) {
+            while (k < 4) {
+                int pick = -1;
+                float area = -1;
+                for (int i = 0; i < k; ++i)
+                    if (!(cr[i] & RT_LEAF_BIT) && cb[i].half_area() > area) { area = cb[i].half_area(); pick = i; }
+                if (pick < 0) break;
+                const Node2& c = nodes2[cr[pick]];
+                cb[k] = c.box[1]; cr[k] = c.child[1];
+                cb[pick] = c.box[0]; cr[pick] = c.child[0];
+                ++k;
+            }
+        } else {
+            const Box sb[2] = {nodes2[n2].box[0], nodes2[n2].box[1]};
+            const uint32_t sr[2] = {nodes2[n2].child[0], nodes2[n2].child[1]};
+            k = 0;
+            for (int side = 0; side < 2; ++side) {
+                if (sr[side] & RT_LEAF_BIT) { cb[k] = sb[side]; cr[k] = sr[side]; ++k; continue; }
+                const Node2& g = nodes2[sr[side]];
+                cb[k] = g.box[0]; cr[k] = g.child[0]; ++k;
+                cb[k] = g.box[1]; cr[k] = g.child[1]; ++k;
+            }
+        }
+        const uint32_t idx = n_nodes++;
+        uint32_t dmax = 0, smax = 0;
+        Bvh4Child out[4];
+        for (int i = 0; i < 4; ++i) {
+            Bvh4Child& c = out[i];
+            c.pad = 0;
+            if (i >= k) { for (int a = 0; a < 3; ++a) { c.lo[a] = INFINITY; c.hi[a] = -INFINITY; } c.ref = RT_NO_CHILD; continue; }
+            pad(cb[i], c.lo, c.hi);
+            if (cr[i] & RT_LEAF_BIT) { c.ref = cr[i]; continue; }
+            uint32_t d = 0, st = 0;
+            c.ref = collapse(cr[i], by_area, d, st);
+            dmax = std::max(dmax, d); smax = std::max(smax, st);
+        }
+        std::memcpy(nodes[idx].c, out, sizeof out);
+        depth = dmax + 1;
+        stack = smax + uint32_t(k - 1);
         return idx;
     }
 
@@ -181,23 +231,40 @@ int bvh_build(const rt_flat_scene* sc, BvhBuildResult* out) {
         const rt_model& md = sc->models[m];
         if (uint64_t(md.first_face) + md.num_faces > nf) return -1;
     }
-    out->nodes = static_cast<BvhNode*>(std::malloc(sizeof(BvhNode) * std::max<size_t>(1, nf)));
+    out->nodes = static_cast<Bvh4Node*>(std::malloc(sizeof(Bvh4Node) * std::max<size_t>(1, nf)));
     out->model_root = static_cast<uint32_t*>(std::malloc(sizeof(uint32_t) * std::max<uint32_t>(1, sc->n_models)));
     out->tris = static_cast<TriIsect*>(std::malloc(sizeof(TriIsect) * std::max<size_t>(1, nf)));
     if (!out->nodes || !out->model_root || !out->tris) { bvh_free(out); return -2; }
     B.nodes = out->nodes;
+    B.nodes2.resize(std::max<size_t>(1, nf));
+    uint32_t max_depth = 0, max_stack = 0;
     for (uint32_t m = 0; m < sc->n_models; ++m) {
         const rt_model& md = sc->models[m];
         if (md.num_faces == 0) { out->model_root[m] = RT_NO_CHILD; continue; }
-        Box bx;
-        uint32_t root = 0;
+        // SAH tree first; if its 4-wide collapse could overflow the traversal stack (pathological geometry), rebuild
+        // this model balanced (median splits, two binary levels per 4-wide level), which cannot.
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            B.balanced = attempt == 1;
+            B.n_nodes2 = 0;
+            const uint32_t nodes_before = B.n_nodes;
+            Box bx;
+            uint32_t root2 = 0;
 #pragma omp parallel
 #pragma omp single
-        root = B.build(md.first_face, md.first_face + md.num_faces, 0, bx);
-        out->model_root[m] = root;
+            root2 = B.build(md.first_face, md.first_face + md.num_faces, 0, bx);
+            uint32_t depth = 0, stack = 0, root = root2;
+            if (!(root2 & RT_LEAF_BIT)) root = B.collapse(root2, !B.balanced, depth, stack);
+            if (stack + 1 > RT_QSTACK && attempt == 0) { B.n_nodes = nodes_before; continue; }
+            if (stack + 1 > RT_QSTACK) { bvh_free(out); return -3; }
+            out->model_root[m] = root;
+            max_depth = std::max(max_depth, depth);
+            max_stack = std::max(max_stack, stack + 1);
+            break;
+        }
     }
-    out->n_nodes = B.n_nodes.load();
-    out->max_depth = B.max_depth.load();
+    out->n_nodes = B.n_nodes;
+    out->max_depth = max_depth;
+    out->max_stack = max_stack;
     out->n_tris = nf;
 #pragma omp parallel for schedule(static)
     for (uint32_t i = 0; i < nf; ++i) {

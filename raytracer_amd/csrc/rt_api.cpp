@@ -47,7 +47,7 @@ struct PassCounters {                 // one per pass, zeroed by one memset per 
     uint32_t overflow;
     uint32_t pad[3];
     unsigned long long shadow[RT_STAT_SHARDS];
-    unsigned long long work[12];
+    unsigned long long work[RT_WORK_SHARDS][2][12];   // per shard: k_extend, k_shade
 };
 
 #define RT_MAX_PASSES 1024
@@ -223,7 +223,7 @@ extern "C" void rt_scene_destroy(rt_scene* s) { free_scene(s); }
 extern "C" int rt_scene_bvh_info(const rt_scene* s, rt_bvh_info* out) {
     if (!s || !out) { rt_set_error("null argument"); return RT_ERR_INVALID; }
     out->n_nodes = s->n_nodes; out->n_faces = s->n_faces; out->max_depth = s->bvh_depth;
-    out->node_bytes = sizeof(BvhNode); out->tri_bytes = sizeof(TriIsect); out->reserved = 0;
+    out->node_bytes = sizeof(Bvh4Node); out->tri_bytes = sizeof(TriIsect); out->reserved = 0;
     out->device_bytes = s->scene_bytes;
     return RT_OK;
 }
@@ -236,6 +236,9 @@ extern "C" int rt_set_count_work(rt_scene* s, int enable) {
 static void add_work(rt_work& w, const unsigned long long* c) {
     w.nodes_visited += c[0]; w.tris_tested += c[1]; w.spheres_tested += c[2]; w.planes_tested += c[3];
     w.wave_node_steps += c[4]; w.wave_tri_steps += c[5];
+    w.trav_ticks_sum += c[6]; w.trav_ticks_max = std::max<uint64_t>(w.trav_ticks_max, c[7]);
+    w.batches += c[8]; w.trav_waves += c[9];
+    w.wave_ticks_sum += c[10]; w.wave_ticks_max = std::max<uint64_t>(w.wave_ticks_max, c[11]);
 }
 extern "C" int rt_get_work(const rt_scene* s, int kernel, rt_work* out) {
     if (!s || !out || kernel < -1 || kernel > 1) { rt_set_error("bad argument"); return RT_ERR_INVALID; }
@@ -244,6 +247,9 @@ extern "C" int rt_get_work(const rt_scene* s, int kernel, rt_work* out) {
     out->nodes_visited = a.nodes_visited + b.nodes_visited; out->tris_tested = a.tris_tested + b.tris_tested;
     out->spheres_tested = a.spheres_tested + b.spheres_tested; out->planes_tested = a.planes_tested + b.planes_tested;
     out->wave_node_steps = a.wave_node_steps + b.wave_node_steps; out->wave_tri_steps = a.wave_tri_steps + b.wave_tri_steps;
+    out->trav_ticks_sum = a.trav_ticks_sum + b.trav_ticks_sum; out->trav_ticks_max = std::max(a.trav_ticks_max, b.trav_ticks_max);
+    out->batches = a.batches + b.batches; out->trav_waves = a.trav_waves + b.trav_waves;
+    out->wave_ticks_sum = a.wave_ticks_sum + b.wave_ticks_sum; out->wave_ticks_max = std::max(a.wave_ticks_max, b.wave_ticks_max);
     return RT_OK;
 }
 
@@ -344,7 +350,7 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
         A.cancelled = pc->cancel;
         A.overflow = &pc->overflow;
         A.shadow_count = pc->shadow;
-        A.work = pc->work;
+        A.work = &pc->work[0][0][0];
         const int levels = s->has_bounce ? A.max_depth : 0;
         const bool overlap = !J.timed && levels >= 1;
         hipStream_t sa = J.st, sb = overlap ? s->shade_stream : J.st;
@@ -359,10 +365,32 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
             B.level = lo; B.level_hi = hi;
             return timed_launch(J, sb, 1, [&] { launch_shade(s->count_work, s->d, B, hi == 0 ? grid0 : RT_LEVEL_GRID, sb); });
         };
+        // diagnostics: RT_WAVE_LOG=<level>:<file> dumps per-workgroup timing of that level's k_extend (COUNT builds)
+        uint4* wave_log = nullptr;
+        int log_level = -1;
+        const char* log_path = nullptr;
+        if (s->count_work) {
+            if (const char* e = std::getenv("RT_WAVE_LOG")) {
+                log_level = std::atoi(e);
+                log_path = std::strchr(e, ':');
+                if (log_path) { ++log_path; hipMalloc(reinterpret_cast<void**>(&wave_log), sizeof(uint4) * std::max(grid0, RT_LEVEL_GRID)); }
+                if (wave_log) hipMemsetAsync(wave_log, 0, sizeof(uint4) * std::max(grid0, RT_LEVEL_GRID), sa);
+            }
+        }
         for (int lv = 0; lv <= levels; ++lv) {
             A.level = lv; A.level_hi = lv;
+            A.wave_log = (lv == log_level) ? wave_log : nullptr;
             if ((rc = timed_launch(J, sa, 0, [&] { launch_extend(lv == 0 ? 0 : 1, s->count_work, s->d, A, lv == 0 ? grid0 : RT_LEVEL_GRID, sa); })) != RT_OK) return rc;
             if (lv <= 1 && (rc = shade(lv, lv, lv)) != RT_OK) return rc;
+        }
+        A.wave_log = nullptr;
+        if (wave_log) {
+            const uint32_t n = (log_level == 0) ? grid0 : RT_LEVEL_GRID;
+            std::vector<uint4> h(n);
+            hipStreamSynchronize(sa);
+            hipMemcpy(h.data(), wave_log, sizeof(uint4) * n, hipMemcpyDeviceToHost);
+            if (FILE* f = std::fopen(log_path, "wb")) { std::fwrite(h.data(), sizeof(uint4), n, f); std::fclose(f); }
+            hipFree(wave_log);
         }
         if (levels >= 2 && (rc = shade(2, levels, 2)) != RT_OK) return rc;
         if (overlap) {
@@ -400,7 +428,7 @@ static int render_frame(rt_scene* s, const rt_camera* cam, const rt_params* prm,
     B.max_depth = prm->max_depth;
     B.spp = spp;
     B.pool_cap = s->pool_cap;
-    if (const char* dbg = std::getenv("RT_DEBUG_SKIP")) B.debug = uint32_t(std::atoi(dbg));   // timing experiments only
+    if (const char* dbg = std::getenv("RT_DEBUG_SKIP")) { B.debug = uint32_t(std::atoi(dbg)); s->d.debug = B.debug; }   // timing experiments only
     B.rays = s->rays; B.node_a = s->node_a; B.node_b = s->node_b; B.hit_n = s->hit_n; B.hit_p = s->hit_p;
     B.aa = s->d_aa;
     std::memcpy(B.background, prm->background, sizeof B.background);
@@ -453,7 +481,7 @@ static int render_frame(rt_scene* s, const rt_camera* cam, const rt_params* prm,
             // level 0: every valid sample is one trace() call; deeper levels: appended entries
             for (int k = 0; k < RT_STAT_SHARDS; ++k) stats->shadow_rays += pc.shadow[k];
             for (int lv = 1; lv < RT_MAX_LEVELS; ++lv) stats->level_rays[lv] += pc.level[lv] - pc.cancel[lv];
-            add_work(w[0], pc.work); add_work(w[1], pc.work + 6);
+            for (int sh = 0; sh < RT_WORK_SHARDS; ++sh) { add_work(w[0], pc.work[sh][0]); add_work(w[1], pc.work[sh][1]); }
         }
         s->last_work[0] = w[0]; s->last_work[1] = w[1];
         stats->passes = uint32_t(final_recs.size());
@@ -657,7 +685,7 @@ static int trace_chunk(rt_scene* s, const rt_params* prm, const float* d_rays, u
     A.n0 = n; A.max_depth = prm->max_depth; A.spp = 1;
     A.counters = s->d_counters->level; A.cancelled = s->d_counters->cancel; A.overflow = &s->d_counters->overflow;
     A.shadow_count = s->d_counters->shadow;
-    A.work = s->d_counters->work;
+    A.work = &s->d_counters->work[0][0][0];
     A.node_a = s->node_a; A.node_b = s->node_b; A.hit_n = s->hit_n; A.hit_p = s->hit_p; A.user_rays = d_rays;
     // pool entry i >= n0 keeps its ray at rays[2*(i-n0)]; the ray array holds pool_cap - ws_n0 entries, so with
     // n0 = n <= ws_n0 the usable pool shrinks accordingly
@@ -684,7 +712,7 @@ static int trace_chunk(rt_scene* s, const rt_params* prm, const float* d_rays, u
         for (int lv = 1; lv < RT_MAX_LEVELS; ++lv) stats->level_rays[lv] += pc.level[lv] - pc.cancel[lv];
         for (int k = 0; k < RT_STAT_SHARDS; ++k) stats->shadow_rays += pc.shadow[k];
         stats->passes += 1;
-        add_work(s->last_work[0], pc.work); add_work(s->last_work[1], pc.work + 6);
+        for (int sh = 0; sh < RT_WORK_SHARDS; ++sh) { add_work(s->last_work[0], pc.work[sh][0]); add_work(s->last_work[1], pc.work[sh][1]); }
     }
     return RT_OK;
 }

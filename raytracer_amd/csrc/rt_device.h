@@ -5,22 +5,24 @@
 
 #include "raytracer_amd.h"
 
-// ---- BVH node, 64 B = half a gfx950 128-B cache line, two per line, 16-B aligned quarters ----
-// Binary node holding the boxes of BOTH children, so one 64-B fetch decides both descents.
-// Child reference: bit 31 clear -> index of another BvhNode; bit 31 set -> leaf:
+// ---- BVH node, 128 B = one gfx950 cache line: 4 children of 32 B each ----
+// A ray is traversed by a QUAD of lanes: lane j of the quad fetches child j (two 16-B loads, the quad's 8 loads cover
+// exactly this line), tests its box, and the quad orders the hit children with cross-lane moves. Leaves hold up to 4
+// triangles, one per lane of the quad. Child reference: bit 31 clear -> index of another Bvh4Node; bit 31 set -> leaf:
 //   bits 0..26 = first triangle (index into the leaf-ordered triangle array), bits 27..30 = count-1.
-struct BvhNode {
-    float lo0[3], hi0[3];
-    float lo1[3], hi1[3];
-    uint32_t child0, child1;
-    uint32_t pad0, pad1;
+// Unused child slots have ref = RT_NO_CHILD.
+struct Bvh4Child {
+    float lo[3]; uint32_t ref;
+    float hi[3]; uint32_t pad;
 };
-static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
+struct Bvh4Node { Bvh4Child c[4]; };
+static_assert(sizeof(Bvh4Node) == 128, "Bvh4Node must be 128 bytes");
 
 #define RT_LEAF_BIT 0x80000000u
 #define RT_LEAF_START_MASK 0x07FFFFFFu
 #define RT_MAX_LEAF_TRIS 4
-#define RT_BVH_MAX_DEPTH 30      // builder guarantee; traversal stack holds 32 entries
+#define RT_BVH2_MAX_DEPTH 30     // depth limit of the binary tree the 4-wide tree is collapsed from
+#define RT_QSTACK 64             // traversal stack entries per ray (LDS); the builder guarantees the tree never needs more
 #define RT_NO_CHILD 0xFFFFFFFFu
 
 // ---- leaf-ordered triangle record for intersection, 48 B: v0 + original face index, e1 = v1-v0, e2 = v2-v0 ----
@@ -52,13 +54,14 @@ static_assert(sizeof(DModel) == 32, "DModel must be 32 bytes");
 
 // Host-side result of the BVH build for all models of a scene.
 struct BvhBuildResult {
-    BvhNode* nodes;        uint32_t n_nodes;
+    Bvh4Node* nodes;       uint32_t n_nodes;
     TriIsect* tris;        uint32_t n_tris;     // leaf order
     uint32_t* model_root;                       // per model
-    uint32_t max_depth;
+    uint32_t max_depth;                         // interior nodes on the longest root-to-leaf path
+    uint32_t max_stack;                         // worst-case traversal stack entries (incl. the sentinel)
 };
 
-// Builds one BVH per model (binned SAH, <= RT_MAX_LEAF_TRIS per leaf, depth <= RT_BVH_MAX_DEPTH) into one shared
-// node array. Returns 0 on success. Caller frees with bvh_free.
+// Builds one BVH per model (binned SAH binary tree, <= RT_MAX_LEAF_TRIS per leaf, collapsed to 4 children per node;
+// worst-case traversal stack <= RT_QSTACK) into one shared node array. Returns 0 on success. Caller frees with bvh_free.
 int bvh_build(const rt_flat_scene* scene, BvhBuildResult* out);
 void bvh_free(BvhBuildResult* r);

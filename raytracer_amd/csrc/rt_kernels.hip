@@ -145,26 +145,28 @@ __device__ __forceinline__ bool tri_isect(V3 v0, V3 e1, V3 e2, const Ray& ray, f
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// BVH traversal. One lane = one ray. The stack of deferred children is split: the first RT_STACK_LDS entries live in
-// LDS, one column per lane (entry [level][lane]: conflict-free, lanes of a wave hit distinct banks); deeper entries
-// go to a private (scratch) array that is touched only by rays that get that deep. 20 LDS entries = 5 KB per wave,
-// so LDS never caps occupancy (160 KB / 32 waves per CU). Depth <= RT_BVH_MAX_DEPTH by construction (bvh_build.cpp).
+// BVH traversal: one ray per QUAD of lanes (16 rays per wave).
+//
+// This workload is bound by the length of dependent chains, not by arithmetic or bandwidth: a frame holds only a few
+// machine-fulls of rays, and a wave that walks 64 divergent rays through a binary tree executes the UNION of their
+// paths, one dependent fetch after the other, while most of the chip idles. So a mesh ray gets four lanes: lane j of
+// the quad fetches and tests child j of a 4-wide node (or triangle j of a leaf), the quad orders the hit children
+// with DPP moves and keeps ONE stack (LDS, [entry][quad]: 16 quads -> 16 banks, the four lanes of a quad broadcast).
+// A wave's traversal then lasts as long as its LONGEST ray, not the union of 64, with ~4x fewer instructions per step
+// on the critical path and half the tree depth.
+//
+// The 64 lanes of the wave are "clients" (one ray each, as everywhere else in the kernels). A mesh object is reached
+// with wave-uniform control flow; the clients that pass the bounding-sphere gate are served 16 at a time: client of
+// rank r goes to quad r%16 in batch r/16, its ray is pulled into the quad's lanes with ds_bpermute and the result is
+// pulled back the same way. No LDS exchange buffers, no barriers.
 // ---------------------------------------------------------------------------------------------------------
-#define RT_STACK_LDS 20
-#define RT_STACK_SPILL (RT_BVH_MAX_DEPTH + 2 - RT_STACK_LDS)
-
-struct Stack {
-    uint32_t* lds;                      // this lane's column
-    uint32_t spill[RT_STACK_SPILL];
-    __device__ __forceinline__ void put(int sp, uint32_t v) {
-        if (sp < RT_STACK_LDS) lds[sp * RT_BLOCK] = v; else spill[sp - RT_STACK_LDS] = v;
-    }
-    __device__ __forceinline__ uint32_t get(int sp) const {
-        return sp < RT_STACK_LDS ? lds[sp * RT_BLOCK] : spill[sp - RT_STACK_LDS];
-    }
+struct Work {
+    uint32_t nodes, tris, spheres, planes, wave_nodes, wave_tris;
+    uint32_t batches;                 // quad-traversal batches this wave ran (COUNT builds)
+    unsigned long long trav_ticks;    // wall-clock ticks (10 ns) this wave spent inside them
+    unsigned long long t_start;       // wave start
+    unsigned long long c_start;       // wave start, core clock
 };
-
-struct Work { uint32_t nodes, tris, spheres, planes, wave_nodes, wave_tris; };
 
 __device__ __forceinline__ uint32_t lane_id();
 // 1 on exactly one active lane of the wave: counts how often the WAVE executes a loop body (COUNT builds)
@@ -192,117 +194,206 @@ __device__ __forceinline__ float safe_rcp(float d) {
 
 #define RT_DONE 0xFFFFFFFFu   // stack sentinel; has the leaf bit set, so the descent loop stops on it too
 
-// ANY = false: closest hit over the model's faces, ties broken by the lower ORIGINAL face index, which is what
-// the reference's ascending strict-< scan keeps (primitives.cpp:376-382). Returns hit; t/u/v/face of the winner.
-// ANY = true : does some face have EPS < t < tmax (the shadow test `hit && tmpdist < ldist`, raytracer.cpp:320-321).
-//
-// Two-phase loop ("while-while"): every lane first descends interior nodes until it holds a leaf, then the lanes
-// test their leaves together. On a 64-wide wave this keeps the node step and the triangle test from being
-// executed back to back for disjoint lane sets in every iteration.
+// quad-local cross-lane moves (DPP quad_perm: no LDS, one VALU instruction each)
+template <int CTRL> __device__ __forceinline__ uint32_t dpp_u(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) { return __uint_as_float(dpp_u<CTRL>(__float_as_uint(v))); }
+#define QP_BCAST(k) ((k) * 0x55)   // every lane of the quad reads lane k
+#define QP_XOR1 0xB1               // [1,0,3,2]
+#define QP_XOR2 0x4E               // [2,3,0,1]
+__device__ __forceinline__ uint32_t quad_max_u(uint32_t v) {
+    v = max(v, dpp_u<QP_XOR1>(v));
+    return max(v, dpp_u<QP_XOR2>(v));
+}
+__device__ __forceinline__ float quad_min_f(float v) {
+    v = fminf(v, dpp_f<QP_XOR1>(v));
+    return fminf(v, dpp_f<QP_XOR2>(v));
+}
+// the 4 predicate bits of this lane's quad
+__device__ __forceinline__ uint32_t quad_bits(bool p, uint32_t lane) {
+    return (uint32_t)(__ballot(p) >> (lane & 60u)) & 15u;
+}
+
+struct QuadHit { float t, u, v; uint32_t face; };   // face == 0xFFFFFFFF: nothing
+
+// Traverses the tree under `root` for the quad's ray (all four lanes hold the same ray; `have` false: idle quad).
+// ANY = false: closest hit, ties broken by the lower ORIGINAL face index, which is what the reference's ascending
+//              strict-< scan keeps (primitives.cpp:376-382). Result (identical in the quad's four lanes) in `out`.
+// ANY = true : is there a face with EPS < t < tmax (the shadow test `hit && tmpdist < ldist`, raytracer.cpp:320-321);
+//              out.face != 0xFFFFFFFF then.
+// `qs` points at this quad's column of the LDS stack (stride 16 words). Called with all 64 lanes active.
 template <bool ANY, bool COUNT>
-__device__ __forceinline__ bool bvh_traverse(const DScene& S, uint32_t root, const Ray& ray, float tmax, float& best_t,
-                                             float& best_u, float& best_v, uint32_t& best_face, Stack& stack,
-                                             Work& wk) {
+__device__ __forceinline__ void quad_traverse(const DScene& S, uint32_t root, bool have, const Ray& ray, float tmax,
+                                              QuadHit& out, uint32_t* qs, Work& wk) {
+    const uint32_t lane = lane_id(), j = lane & 3u;
     // culling direction: a zero (or denormal) component is replaced by +-1e-30 so that lo*inv - o*inv keeps the sign of
     // lo - o instead of becoming inf - inf; only the box tests use it, the triangle test gets the ray as it is
     const V3 inv = mk(safe_rcp(ray.d.x), safe_rcp(ray.d.y), safe_rcp(ray.d.z));
     const V3 ood = mk(ray.o.x * inv.x, ray.o.y * inv.y, ray.o.z * inv.z);
-    float best = ANY ? tmax : FLT_MAX;
-    float tcull = best;
-    bool found = false;
+    float best = ANY ? tmax : FLT_MAX, bu = 0, bv = 0;      // this LANE's best candidate
     uint32_t face = 0xFFFFFFFFu;
-    float bu = 0, bv = 0;
-    stack.put(0, RT_DONE);
+    float tcull = best;                                      // the quad's culling distance
+    if (j == 0) qs[0] = RT_DONE;
     int sp = 1;
-    uint32_t cur = root;       // RT_NO_CHILD == RT_DONE for an empty model
+    uint32_t cur = have ? root : RT_DONE;      // RT_NO_CHILD == RT_DONE for an empty model
     while (cur != RT_DONE) {
         while (!(cur & RT_LEAF_BIT)) {
-            const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
-            const float4 a = np[0], b = np[1], c = np[2];
-            const uint4 r = reinterpret_cast<const uint4*>(np)[3];
-            if (COUNT) { wk.nodes++; wk.wave_nodes += wave_once(); }
-            bool h0, h1;
-            const float t0 = slab(a.x, a.y, a.z, a.w, b.x, b.y, inv, ood, tcull, h0);
-            const float t1 = slab(b.z, b.w, c.x, c.y, c.z, c.w, inv, ood, tcull, h1);
-            if (h0 && h1) {
-                const bool first0 = t0 <= t1;
-                stack.put(sp, first0 ? r.y : r.x);
-                ++sp;
-                cur = first0 ? r.x : r.y;
-            } else if (h0 || h1) {
-                cur = h0 ? r.x : r.y;
-            } else {
-                --sp;
-                cur = stack.get(sp);
-            }
+            const float4* np = reinterpret_cast<const float4*>(S.nodes + cur) + 2 * j;
+            const float4 a = np[0], b = np[1];
+            if (COUNT) { wk.nodes += (j == 0); wk.wave_nodes += wave_once(); }
+            const uint32_t ref = __float_as_uint(a.w);
+            bool h;
+            float tn = slab(a.x, a.y, a.z, b.x, b.y, b.z, inv, ood, tcull, h);
+            h = h && ref != RT_NO_CHILD;
+            tn = h ? tn : FLT_MAX;
+            const uint32_t bits = quad_bits(h, lane);
+            const uint32_t n_hit = (uint32_t)__popc(bits);
+            // rank of this lane's child among the hit ones, nearest first (ties: lower slot first)
+            const float t0 = dpp_f<QP_BCAST(0)>(tn), t1 = dpp_f<QP_BCAST(1)>(tn), t2 = dpp_f<QP_BCAST(2)>(tn), t3 = dpp_f<QP_BCAST(3)>(tn);
+            const uint32_t rank = (uint32_t)(t0 < tn || (t0 == tn && 0u < j)) + (uint32_t)(t1 < tn || (t1 == tn && 1u < j)) +
+                                  (uint32_t)(t2 < tn || (t2 == tn && 2u < j)) + (uint32_t)(t3 < tn);
+            // the nearest is visited next, the others are pushed so that the second nearest is on top
+            if (h && rank > 0) qs[(sp + (int)n_hit - 1 - (int)rank) * 16] = ref;
+            cur = quad_max_u((h && rank == 0) ? ref : 0u);     // a child reference is never 0 (node 0 is a root)
+            if (n_hit == 0) { --sp; cur = qs[sp * 16]; }
+            else sp += (int)n_hit - 1;
         }
         if (cur != RT_DONE) {
             const uint32_t start = cur & RT_LEAF_START_MASK;
             const uint32_t cnt = ((cur >> 27) & 15u) + 1u;
             --sp;
-            cur = stack.get(sp);
-            for (uint32_t i = 0; i < cnt; ++i) {
-                const float4* tp = reinterpret_cast<const float4*>(S.tris + (start + i));
+            cur = qs[sp * 16];
+            if (COUNT) { wk.tris += (j < cnt); wk.wave_tris += wave_once(); }
+            bool got = false;
+            if (j < cnt) {
+                const float4* tp = reinterpret_cast<const float4*>(S.tris + (start + j));
                 const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
-                if (COUNT) { wk.tris++; wk.wave_tris += wave_once(); }
                 float t, u, v;
                 if (tri_isect(f4xyz(q0), f4xyz(q1), f4xyz(q2), ray, t, u, v)) {
                     const uint32_t f = __float_as_uint(q0.w);
                     if (ANY) {
-                        if (t < tmax) { found = true; cur = RT_DONE; }
+                        got = t < tmax;
                     } else if (t < best || (t == best && f < face)) {
-                        best = t; bu = u; bv = v; face = f; found = true;
-                        tcull = t * 1.000001f;
+                        best = t; bu = u; bv = v; face = f;
                     }
                 }
             }
+            if (ANY) {
+                if (quad_bits(got, lane)) { face = 0; cur = RT_DONE; }
+            } else {
+                tcull = quad_min_f(best) * 1.000001f;
+            }
         }
     }
-    if (!ANY && found) { best_t = best; best_u = bu; best_v = bv; best_face = face; }
-    return found;
+    if (!ANY) {
+        // the quad's winner: lexicographic minimum of (t, face) over its four lanes
+        {
+            const float ot = dpp_f<QP_XOR1>(best), ou = dpp_f<QP_XOR1>(bu), ov = dpp_f<QP_XOR1>(bv);
+            const uint32_t of = dpp_u<QP_XOR1>(face);
+            if (ot < best || (ot == best && of < face)) { best = ot; bu = ou; bv = ov; face = of; }
+        }
+        {
+            const float ot = dpp_f<QP_XOR2>(best), ou = dpp_f<QP_XOR2>(bu), ov = dpp_f<QP_XOR2>(bv);
+            const uint32_t of = dpp_u<QP_XOR2>(face);
+            if (ot < best || (ot == best && of < face)) { best = ot; bu = ou; bv = ov; face = of; }
+        }
+    }
+    out.t = best; out.u = bu; out.v = bv; out.face = face;
+}
+
+// Serves the clients in `need` (wave-wide, convergent): each gets the QuadHit of its ray against the tree under root.
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ QuadHit wave_traverse(const DScene& S, uint32_t root, bool need, const Ray& ray, float tmax,
+                                                 uint32_t* lds_stack, Work& wk) {
+    QuadHit res;
+    res.t = FLT_MAX; res.u = 0; res.v = 0; res.face = 0xFFFFFFFFu;
+    const unsigned long long mask = __ballot(need);
+    if (mask == 0) return res;
+    const uint32_t lane = lane_id();
+    const int n_need = __popcll(mask);
+    const int rank = __popcll(mask & ((1ull << lane) - 1ull));
+    uint32_t* qs = lds_stack + (lane >> 2);
+    unsigned long long c0 = 0;
+    if (COUNT) c0 = wall_clock64();
+    for (int b0 = 0; b0 < n_need; b0 += 16) {
+        if (COUNT) wk.batches++;
+        // client -> quad: the client of rank b0+q tells lane 4q (the quad's first lane) who it is; everybody else
+        // writes to an odd lane, which nobody reads
+        const bool mine = need && rank >= b0 && rank < b0 + 16;
+        const int dest = mine ? 4 * (rank - b0) : (int)(lane | 1u);
+        const uint32_t told = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)(lane + 1u));
+        const uint32_t client1 = dpp_u<QP_BCAST(0)>(told);          // client lane + 1, or 0: idle quad
+        const bool have = client1 != 0u;
+        const int src = (int)((have ? client1 - 1u : lane) << 2);
+        Ray qr;
+        qr.o.x = __uint_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_uint(ray.o.x)));
+        qr.o.y = __uint_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_uint(ray.o.y)));
+        qr.o.z = __uint_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_uint(ray.o.z)));
+        qr.d.x = __uint_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_uint(ray.d.x)));
+        qr.d.y = __uint_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_uint(ray.d.y)));
+        qr.d.z = __uint_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_uint(ray.d.z)));
+        float qmax = FLT_MAX;
+        if (ANY) qmax = __uint_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_uint(tmax)));
+        QuadHit qh;
+        quad_traverse<ANY, COUNT>(S, root, have, qr, qmax, qh, qs, wk);
+        // quad -> client
+        const int back = (mine ? 4 * (rank - b0) : (int)lane) << 2;
+        const uint32_t f = (uint32_t)__builtin_amdgcn_ds_bpermute(back, (int)qh.face);
+        if (ANY) {
+            if (mine) res.face = f;
+        } else {
+            const float t = __uint_as_float(__builtin_amdgcn_ds_bpermute(back, __float_as_uint(qh.t)));
+            const float u = __uint_as_float(__builtin_amdgcn_ds_bpermute(back, __float_as_uint(qh.u)));
+            const float v = __uint_as_float(__builtin_amdgcn_ds_bpermute(back, __float_as_uint(qh.v)));
+            if (mine) { res.t = t; res.u = u; res.v = v; res.face = f; }
+        }
+    }
+    if (COUNT) wk.trav_ticks += wall_clock64() - c0;
+    return res;
 }
 
 // Model::intersect (reference src/primitives.cpp:364-384): dist = FLT_MAX, bounding-sphere gate, closest face,
-// normal = (1-u-v)*n0 + u*n1 + v*n2 (primitives.cpp:80, not normalised).
+// normal = (1-u-v)*n0 + u*n1 + v*n2 (primitives.cpp:80, not normalised). Convergent: every lane of the wave calls it,
+// `alive` says whether the lane has a ray; dist/normal are touched only for alive lanes.
 template <bool COUNT>
-__device__ __forceinline__ bool model_closest(const DScene& S, const ModelRef& m, const Ray& ray, float& dist, V3& normal,
-                                              Stack& stack, Work& wk) {
-    dist = FLT_MAX;
+__device__ __forceinline__ bool model_closest(const DScene& S, const ModelRef& m, const Ray& ray, bool alive, float& dist,
+                                              V3& normal, uint32_t* lds_stack, Work& wk) {
+    bool need = alive;
+    if (alive) dist = FLT_MAX;
     if (m.bb.w >= 0) {
-        if (COUNT) wk.spheres++;
-        if (!sphere_gate(m.bb, ray)) return false;
+        if (COUNT) wk.spheres += alive;
+        need = alive && sphere_gate(m.bb, ray);
     }
-    float t, u, v;
-    uint32_t face;
-    const bool got = bvh_traverse<false, COUNT>(S, m.root, ray, FLT_MAX, t, u, v, face, stack, wk);
-    if (!got) return false;
-    const float4* np = reinterpret_cast<const float4*>(S.normals + face);
-    const V3 n0 = f4xyz(np[0]), n1 = f4xyz(np[1]), n2 = f4xyz(np[2]);
-    dist = t;
-    normal = (n0 * (1 - u - v) + n1 * u) + n2 * v;
-    return true;   // every accepted face already satisfied dist > EPS
+    const QuadHit h = wave_traverse<false, COUNT>(S, m.root, need, ray, FLT_MAX, lds_stack, wk);
+    const bool got = need && h.face != 0xFFFFFFFFu;
+    if (got) {
+        const float4* np = reinterpret_cast<const float4*>(S.normals + h.face);
+        const V3 n0 = f4xyz(np[0]), n1 = f4xyz(np[1]), n2 = f4xyz(np[2]);
+        dist = h.t;
+        normal = (n0 * (1 - h.u - h.v) + n1 * h.u) + n2 * h.v;
+    }
+    return got;   // every accepted face already satisfied dist > EPS
 }
 template <bool COUNT>
-__device__ __forceinline__ bool model_any(const DScene& S, const ModelRef& m, const Ray& ray, float tmax, Stack& stack,
-                                          Work& wk) {
+__device__ __forceinline__ bool model_any(const DScene& S, const ModelRef& m, const Ray& ray, bool alive, float tmax,
+                                          uint32_t* lds_stack, Work& wk) {
+    bool need = alive;
     if (m.bb.w >= 0) {
-        if (COUNT) wk.spheres++;
-        if (!sphere_gate(m.bb, ray)) return false;
+        if (COUNT) wk.spheres += alive;
+        need = alive && sphere_gate(m.bb, ray);
     }
-    float t, u, v;
-    uint32_t face;
-    const bool got = bvh_traverse<true, COUNT>(S, m.root, ray, tmax, t, u, v, face, stack, wk);
-    return got;
+    const QuadHit h = wave_traverse<true, COUNT>(S, m.root, need, ray, tmax, lds_stack, wk);
+    return need && h.face != 0xFFFFFFFFu;
 }
 
 // Closest-hit loop of trace() (reference src/raytracer.cpp:292-300): objects in scene order, strict <.
-// The object table is read with wave-uniform indices (scalar loads); only the per-lane tests diverge.
 // Object table entry k = two uint4: {type, index, material, sphere 1/r bits} and the float4 parameters of a sphere
 // (cx cy cz r) or plane (a b c d). The index k is wave-uniform, so both come in by scalar loads; the next entry is
-// requested before the current one is worked on.
+// requested before the current one is worked on. Convergent: all 64 lanes call it, `alive` marks lanes with a ray.
 template <bool COUNT>
-__device__ __forceinline__ int closest_hit(const DScene& S, const Ray& ray, float& dist, V3& hitNormal, float& tmpdist,
-                                           uint32_t& material, Stack& stack, Work& wk) {
+__device__ __forceinline__ int closest_hit(const DScene& S, const Ray& ray, bool alive, float& dist, V3& hitNormal,
+                                           float& tmpdist, uint32_t& material, uint32_t* lds_stack, Work& wk) {
     dist = FLT_MAX;
     int cur = -1;
     material = 0;
@@ -313,15 +404,15 @@ __device__ __forceinline__ int closest_hit(const DScene& S, const Ray& ray, floa
         const uint32_t kn = k + 1 < S.n_objects ? k + 1 : k;
         const u32x4 ob_n = ldc4(S.objects, 2 * kn), pb_n = ldc4(S.objects, 2 * kn + 1);
         const float4 prm = as_f4(pb);
-        bool hit;
+        bool hit = false;
         if (ob.x == RT_OBJ_SPHERE) {
-            if (COUNT) wk.spheres++;
-            hit = sphere_isect(prm, __uint_as_float(ob.w), ray, tmpdist, tmpnormal);
+            if (COUNT) wk.spheres += alive;
+            if (alive && !(S.debug & 16u)) hit = sphere_isect(prm, __uint_as_float(ob.w), ray, tmpdist, tmpnormal);
         } else if (ob.x == RT_OBJ_PLANE) {
-            if (COUNT) wk.planes++;
-            hit = plane_isect(prm, ray, tmpdist, tmpnormal);
+            if (COUNT) wk.planes += alive;
+            if (alive && !(S.debug & 16u)) hit = plane_isect(prm, ray, tmpdist, tmpnormal);
         } else {
-            hit = model_closest<COUNT>(S, load_model(S.models, ob.y), ray, tmpdist, tmpnormal, stack, wk);
+            hit = model_closest<COUNT>(S, load_model(S.models, ob.y), ray, alive && !(S.debug & 8u), tmpdist, tmpnormal, lds_stack, wk);
         }
         if (hit && tmpdist < dist) {
             dist = tmpdist;
@@ -334,10 +425,11 @@ __device__ __forceinline__ int closest_hit(const DScene& S, const Ray& ray, floa
     return cur;
 }
 
-// Shadow loop of trace() (reference src/raytracer.cpp:319-325): any object with hit && tmpdist < ldist.
+// Shadow loop of trace() (reference src/raytracer.cpp:319-325): any object with hit && tmpdist < ldist; the loop
+// breaks at the first one, so later objects no longer touch tmpdist. Convergent like closest_hit.
 template <bool COUNT>
-__device__ __forceinline__ bool occluded(const DScene& S, const Ray& ray, float ldist, float& tmpdist, Stack& stack,
-                                         Work& wk) {
+__device__ __forceinline__ bool occluded(const DScene& S, const Ray& ray, bool alive, float ldist, float& tmpdist,
+                                         uint32_t* lds_stack, Work& wk) {
     V3 tmpnormal;
     bool in = false;
     if (S.n_objects == 0) return in;
@@ -346,17 +438,23 @@ __device__ __forceinline__ bool occluded(const DScene& S, const Ray& ray, float 
         const uint32_t kn = k + 1 < S.n_objects ? k + 1 : k;
         const u32x4 ob_n = ldc4(S.objects, 2 * kn), pb_n = ldc4(S.objects, 2 * kn + 1);
         const float4 prm = as_f4(pb);
-        if (!in) {
-            if (ob.x == RT_OBJ_SPHERE) {
-                if (COUNT) wk.spheres++;
+        const bool go = alive && !in;
+        if (ob.x == RT_OBJ_SPHERE) {
+            if (COUNT) wk.spheres += go;
+            if (go) {
                 const bool hit = sphere_isect(prm, __uint_as_float(ob.w), ray, tmpdist, tmpnormal);
                 in = hit && tmpdist < ldist;
-            } else if (ob.x == RT_OBJ_PLANE) {
-                if (COUNT) wk.planes++;
+            }
+        } else if (ob.x == RT_OBJ_PLANE) {
+            if (COUNT) wk.planes += go;
+            if (go) {
                 const bool hit = plane_isect(prm, ray, tmpdist, tmpnormal);
                 in = hit && tmpdist < ldist;
-            } else {
-                in = model_any<COUNT>(S, load_model(S.models, ob.y), ray, ldist, stack, wk);
+            }
+        } else {
+            const bool any = model_any<COUNT>(S, load_model(S.models, ob.y), ray, go, ldist, lds_stack, wk);
+            if (go) {
+                in = any;
                 if (!in) tmpdist = FLT_MAX;   // Model::intersect leaves FLT_MAX in dist on a miss (primitives.cpp:368)
             }
         }
@@ -496,10 +594,18 @@ __device__ __forceinline__ uint32_t rays_per_wave(uint32_t n_items) {
     return per < 1u ? 1u : (per < RT_BLOCK ? per : RT_BLOCK);
 }
 
-__device__ __forceinline__ void flush_work(unsigned long long* out, const Work& wk) {
+__device__ __forceinline__ void flush_work(unsigned long long* work, uint32_t kernel, const Work& wk) {
+    unsigned long long* out = work + ((blockIdx.x & (RT_WORK_SHARDS - 1)) * 2 + kernel) * 12;   // sharded like shadow_count
     const uint32_t a = wave_sum(wk.nodes), b = wave_sum(wk.tris), c = wave_sum(wk.spheres), d = wave_sum(wk.planes);
     const uint32_t e = wave_sum(wk.wave_nodes), f = wave_sum(wk.wave_tris);
     if (lane_id() == 0) {
+        const unsigned long long life = wall_clock64() - wk.t_start;
+        atomicAdd(out + 6, wk.trav_ticks);
+        atomicMax(out + 7, wk.trav_ticks);
+        atomicAdd(out + 8, (unsigned long long)wk.batches);
+        atomicAdd(out + 9, wk.batches ? 1ull : 0ull);
+        atomicAdd(out + 10, life);
+        atomicMax(out + 11, life);
         atomicAdd(out + 0, (unsigned long long)a);
         atomicAdd(out + 1, (unsigned long long)b);
         atomicAdd(out + 2, (unsigned long long)c);
@@ -511,15 +617,14 @@ __device__ __forceinline__ void flush_work(unsigned long long* out, const Work& 
 
 template <int SRC, bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK) void k_extend(DScene S, LevelArgs A) {
-    __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
-    Stack stack;
-    stack.lds = lds_stack + threadIdx.x;
+    __shared__ uint32_t lds_stack[RT_QSTACK * 16];
 
     uint32_t begin = 0, end = A.n0;
     if (SRC == 1) level_range(A, A.level, A.level, begin, end);
     const uint32_t next_base = end;               // children of this level are appended behind it
     uint32_t* next_count = A.counters + (A.level + 1);
-    Work wk = {0, 0, 0, 0, 0, 0};
+    Work wk = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (COUNT) { wk.t_start = wall_clock64(); wk.c_start = clock64(); }
 
     const uint32_t n_items = end - begin;
     const uint32_t R = SRC == 1 ? rays_per_wave(n_items) : RT_BLOCK;
@@ -552,12 +657,12 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(DScene S, LevelArgs A) {
         V3 hitNormal = mk(0, 0, 0), hitPt = mk(0, 0, 0);
         float tmpdist = 0, rCoef = 0;     // tmpdist: uninitialised in the reference (raytracer.cpp:285); defined as 0
 
+        float dist = FLT_MAX;
+        uint32_t mat_id = 0;
+        int cur = -1;
+        if (!(A.debug & 2u)) cur = closest_hit<COUNT>(S, ray, valid, dist, hitNormal, tmpdist, mat_id, lds_stack, wk);
+        if (A.debug & 4u) cur = -1;
         if (valid) {
-            float dist;
-            uint32_t mat_id;
-            int cur = -1;
-            if (!(A.debug & 2u)) cur = closest_hit<COUNT>(S, ray, dist, hitNormal, tmpdist, mat_id, stack, wk);
-            if (A.debug & 4u) cur = -1;
             rec_b.w = NODE_VALID;
             if (cur >= 0) {
                 const rt_material* mp = S.materials + mat_id;
@@ -633,19 +738,20 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(DScene S, LevelArgs A) {
             }
         }
     }
-    if (COUNT) flush_work(A.work, wk);
+    if (COUNT) flush_work(A.work, 0, wk);
+    if (COUNT && A.wave_log && lane_id() == 0)
+        A.wave_log[blockIdx.x] = make_uint4((uint32_t)wk.t_start, (uint32_t)wall_clock64(), (uint32_t)wk.trav_ticks, (uint32_t)(clock64() - wk.c_start));
 }
 
 // Light loop of trace() (reference src/raytracer.cpp:311-345) for the hits of levels A.level..A.level_hi.
 template <bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK) void k_shade(DScene S, LevelArgs A) {
-    __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
-    Stack stack;
-    stack.lds = lds_stack + threadIdx.x;
+    __shared__ uint32_t lds_stack[RT_QSTACK * 16];
 
     uint32_t begin = 0, end = A.n0;
     if (A.level_hi > 0) level_range(A, A.level, A.level_hi, begin, end);
-    Work wk = {0, 0, 0, 0, 0, 0};
+    Work wk = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (COUNT) { wk.t_start = wall_clock64(); wk.c_start = clock64(); }
     uint32_t n_shadow = 0;
 
     const uint32_t n_items = end - begin;
@@ -656,8 +762,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DScene S, LevelArgs A) {
         const bool active = threadIdx.x < R && i < end;
         uint4 b = make_uint4(0, 0, 0, 0);
         if (active) b = A.node_b[i];
-        if (!(b.w & NODE_HIT)) continue;
-        const float4 hn = A.hit_n[i], hp = A.hit_p[i];
+        const bool hit = (b.w & NODE_HIT) != 0;
+        if (!__any(hit)) continue;                                                           // wave-uniform
+        float4 hn = make_float4(0, 0, 0, 0), hp = make_float4(0, 0, 0, 0);
+        if (hit) { hn = A.hit_n[i]; hp = A.hit_p[i]; }
         const V3 hitNormal = f4xyz(hn), hitPt = f4xyz(hp);
         float tmpdist = hn.w;
         const float rCoef = hp.w;
@@ -665,7 +773,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DScene S, LevelArgs A) {
         const float bias = 0.0001f;                                                          // raytracer.cpp:286
         V3 color = mk(0, 0, 0);
         bool red = false;
-        for (uint32_t li = 0; li < S.n_lights && !red; ++li) {                               // raytracer.cpp:311-345
+        // the light loop runs convergent (the mesh traversal inside occluded() is a wave-level operation); `live`
+        // says whether this lane is still in ITS light loop
+        for (uint32_t li = 0; li < S.n_lights; ++li) {                                       // raytracer.cpp:311-345
+            const bool live = hit && !red;
             const float4 lp = as_f4(ldc4(S.lights, 2 * li)), lc = as_f4(ldc4(S.lights, 2 * li + 1));
             V3 lv = f4xyz(lp) - hitPt;
             const float ldist = length(lv);
@@ -673,10 +784,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DScene S, LevelArgs A) {
             Ray sr;
             sr.o = hitPt + hitNormal * bias;
             sr.d = lv;
-            ++n_shadow;
-            const bool occ = (A.debug & 1u) ? false : occluded<COUNT>(S, sr, ldist, tmpdist, stack, wk);
-            if (occ) continue;
-            if (isnan3(hitNormal)) { red = true; break; }                                    // raytracer.cpp:330-332
+            n_shadow += live;
+            const bool occ = occluded<COUNT>(S, sr, live && !(A.debug & 1u), ldist, tmpdist, lds_stack, wk);
+            if (!live || occ) continue;
+            if (isnan3(hitNormal)) { red = true; continue; }                                 // raytracer.cpp:330-332
             const float cosPhi = max_std(dot(hitNormal, lv), 0.0f);
             const float fd = cosPhi / (ldist * ldist);
             color = color + mk(((m.color[0] * lc.x) * m.kd) * fd, ((m.color[1] * lc.y) * m.kd) * fd,
@@ -686,6 +797,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DScene S, LevelArgs A) {
             const float fs = (float)(spec_pow((double)cosAlpha, m.specRefExp) / (double)(ldist * ldist));
             color = color + mk((lc.x * m.ks) * fs, (lc.y * m.ks) * fs, (lc.z * m.ks) * fs);
         }
+        if (!hit) continue;
         if (red) {
             A.node_a[i] = make_float4(1, 0, 0, 0);
             if (b.w & NODE_FOLD) {      // children were appended speculatively: ignore them, and un-count them
@@ -706,7 +818,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(DScene S, LevelArgs A) {
     // statistics: one atomic per wave, spread over RT_STAT_SHARDS words
     const uint32_t ns = wave_sum(n_shadow);
     if (lane_id() == 0 && ns) atomicAdd(A.shadow_count + (blockIdx.x & (RT_STAT_SHARDS - 1)), (unsigned long long)ns);
-    if (COUNT) flush_work(A.work + 6, wk);
+    if (COUNT) flush_work(A.work, 1, wk);
 }
 
 // Colour of pool node i once its children (one level deeper) are final.
@@ -800,30 +912,30 @@ __global__ __launch_bounds__(RT_BLOCK) void k_cast_rays(DCamera cam, const float
 __global__ __launch_bounds__(RT_BLOCK) void k_intersect(DScene S, int object, const float* __restrict__ rays, uint32_t n,
                                                         int32_t* __restrict__ hit_obj, float* __restrict__ dist_out,
                                                         float* __restrict__ normal_out) {
-    __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
-    Stack stack;
-    stack.lds = lds_stack + threadIdx.x;
+    __shared__ uint32_t lds_stack[RT_QSTACK * 16];
     const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
-    if (i >= n) return;
+    const bool alive = i < n;
     Ray ray;
-    ray.o = ld3(rays + 6 * (size_t)i); ray.d = ld3(rays + 6 * (size_t)i + 3);
-    Work wk = {0, 0, 0, 0, 0, 0};
+    ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 0);
+    if (alive) { ray.o = ld3(rays + 6 * (size_t)i); ray.d = ld3(rays + 6 * (size_t)i + 3); }
+    Work wk = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     float d = 0;
     V3 nrm = mk(0, 0, 0);
     int hit = -1;
     if (object >= 0) {
         const u32x4 ob = ldc4(S.objects, 2 * object), pb = ldc4(S.objects, 2 * object + 1);
         const float4 prm = as_f4(pb);
-        bool h;
-        if (ob.x == RT_OBJ_SPHERE) h = sphere_isect(prm, __uint_as_float(ob.w), ray, d, nrm);
-        else if (ob.x == RT_OBJ_PLANE) h = plane_isect(prm, ray, d, nrm);
-        else h = model_closest<false>(S, load_model(S.models, ob.y), ray, d, nrm, stack, wk);
+        bool h = false;
+        if (ob.x == RT_OBJ_SPHERE) { if (alive) h = sphere_isect(prm, __uint_as_float(ob.w), ray, d, nrm); }
+        else if (ob.x == RT_OBJ_PLANE) { if (alive) h = plane_isect(prm, ray, d, nrm); }
+        else h = model_closest<false>(S, load_model(S.models, ob.y), ray, alive, d, nrm, lds_stack, wk);
         if (h) hit = object;
     } else {
         float tmp = 0;
         uint32_t mat;
-        hit = closest_hit<false>(S, ray, d, nrm, tmp, mat, stack, wk);
+        hit = closest_hit<false>(S, ray, alive, d, nrm, tmp, mat, lds_stack, wk);
     }
+    if (!alive) return;
     hit_obj[i] = hit;
     dist_out[i] = d;
     normal_out[3 * (size_t)i] = nrm.x; normal_out[3 * (size_t)i + 1] = nrm.y; normal_out[3 * (size_t)i + 2] = nrm.z;
@@ -831,16 +943,17 @@ __global__ __launch_bounds__(RT_BLOCK) void k_intersect(DScene S, int object, co
 
 __global__ __launch_bounds__(RT_BLOCK) void k_occluded(DScene S, const float* __restrict__ rays, const float* __restrict__ max_dist,
                                                        uint32_t n, uint8_t* __restrict__ occ) {
-    __shared__ uint32_t lds_stack[RT_STACK_LDS * RT_BLOCK];
-    Stack stack;
-    stack.lds = lds_stack + threadIdx.x;
+    __shared__ uint32_t lds_stack[RT_QSTACK * 16];
     const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
-    if (i >= n) return;
+    const bool alive = i < n;
     Ray ray;
-    ray.o = ld3(rays + 6 * (size_t)i); ray.d = ld3(rays + 6 * (size_t)i + 3);
-    Work wk = {0, 0, 0, 0, 0, 0};
+    ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 0);
+    float md = 0;
+    if (alive) { ray.o = ld3(rays + 6 * (size_t)i); ray.d = ld3(rays + 6 * (size_t)i + 3); md = max_dist[i]; }
+    Work wk = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     float tmp = 0;
-    occ[i] = occluded<false>(S, ray, max_dist[i], tmp, stack, wk) ? 1 : 0;
+    const bool in = occluded<false>(S, ray, alive, md, tmp, lds_stack, wk);
+    if (alive) occ[i] = in ? 1 : 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------

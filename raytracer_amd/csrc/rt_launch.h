@@ -7,6 +7,7 @@
 
 #define RT_BLOCK 64          // one wave per workgroup: waves retire independently, no barrier is ever needed
 #define RT_MAX_LEVELS 16     // recursion levels 0..max_depth, max_depth <= 15
+#define RT_WORK_SHARDS 64      // COUNT builds: [shard][kernel 0/1][12] words
 #define RT_STAT_SHARDS 256    // statistics atomics are spread over this many words: one word saturates at ~90 atomics/us
 
 // Scene in HBM (SoA). All pointers are device pointers owned by rt_scene.
@@ -14,10 +15,12 @@ struct DScene {
     const uint4* objects;        // 2 per object, scene order: {type, index, material, sphere 1/r bits}, {4 float params}
     uint32_t n_objects;
     uint32_t n_lights;
+    uint32_t debug;              // timing experiments only (RT_DEBUG_SKIP)
+    uint32_t pad;
     const DModel* models;
     const rt_material* materials;
     const float4* lights;        // 2 per light: pos, color
-    const BvhNode* nodes;
+    const Bvh4Node* nodes;
     const TriIsect* tris;        // leaf order
     const TriNormals* normals;   // original face order
 };
@@ -59,7 +62,7 @@ struct LevelArgs {
     uint32_t* cancelled;         // [RT_MAX_LEVELS+1] per level: speculative children whose parent took the red exit
     uint32_t* overflow;          // set to 1 if a child did not fit
     unsigned long long* shadow_count;   // [RT_STAT_SHARDS], indexed by workgroup
-    unsigned long long* work;    // [6] lane nodes, tris, spheres, planes, wave node steps, wave tri steps (COUNT builds)
+    unsigned long long* work;    // [RT_WORK_SHARDS][2][12] traversal work counters (COUNT builds only)
     float4* rays;                // 2 per pool entry >= n0: origin, direction
     float4* node_a;              // per pool entry: r g b rCoef
     uint4* node_b;               // per pool entry: refl child, refr child, material, flags
@@ -69,6 +72,7 @@ struct LevelArgs {
     const float* user_rays;      // SRC 2
     float background[3];
     uint32_t debug;              // timing experiments only (RT_DEBUG_SKIP)
+    uint4* wave_log;             // diagnostics (COUNT builds, RT_WAVE_LOG): per workgroup {start, end, traversal ticks, batches}
     PixelMap pm;
     DCamera cam;
 };

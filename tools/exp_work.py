@@ -1,4 +1,4 @@
-"""Diagnostic: traversal work counters per recursion level (differences of frames rendered at max_depth d and d-1)."""
+"""Diagnostic: traversal work counters per recursion level and kernel (differences of frames at max_depth d and d-1)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -8,14 +8,20 @@ name = sys.argv[1] if len(sys.argv) > 1 else "bunny_1080p"
 fs, cam, p = wl.make_workload(name)
 dev = DeviceScene(fs)
 dev.set_count_work(True)
-prev = np.zeros(6, np.int64)
-for d in range(0, 4):
+F = ["nodes_visited", "tris_tested", "wave_node_steps", "wave_tri_steps", "trav_ticks_sum", "batches", "trav_waves", "wave_ticks_sum"]
+prev = {0: np.zeros(len(F), np.int64), 1: np.zeros(len(F), np.int64)}
+prays = np.zeros(2, np.int64)
+for d in range(0, 3):
     pp = Params(max_depth=d, aa=p.aa)
     _, st = dev.render(cam, pp)
-    w = dev.get_work()
-    cur = np.array([w.nodes_visited, w.tris_tested, w.wave_node_steps, w.wave_tri_steps, st.trace_calls, st.shadow_rays], np.int64)
-    dl = cur - prev
-    prev = cur
-    rays = dl[4] + dl[5]
-    print(f"skip={os.environ.get('RT_DEBUG_SKIP','0')} level {d}: trace {dl[4]} shadow {dl[5]} | lane nodes {dl[0]} ({dl[0]/max(rays,1):.1f}/ray) tris {dl[1]} ({dl[1]/max(rays,1):.1f}/ray)"
-          f" | wave node steps {dl[2]} tri steps {dl[3]} | lanes/step nodes {dl[0]/max(dl[2],1):.1f} tris {dl[1]/max(dl[3],1):.1f}")
+    rays = np.array([st.trace_calls, st.shadow_rays], np.int64)
+    for k, kn in ((0, "extend"), (1, "shade ")):
+        w = dev.get_work(k)
+        cur = np.array([getattr(w, f) for f in F], np.int64)
+        dl = cur - prev[k]; prev[k] = cur
+        r = rays[k] - prays[k]
+        print(f"L{d} {kn}: rays {r} | quad nodes {dl[0]} ({dl[0]/max(r,1):.2f}/ray) tris {dl[1]} | wave steps node {dl[2]} tri {dl[3]}"
+              f" | batches {dl[5]} in {dl[6]} waves, {dl[2]/max(dl[5],1):.1f} node + {dl[3]/max(dl[5],1):.1f} tri steps/batch,"
+              f" {dl[4]*0.01/max(dl[5],1):.2f} us/batch, trav max/wave {w.trav_ticks_max*0.01:.1f} us (cumulative)"
+              f" | wave life sum {dl[7]*0.01/1e3:.1f} ms, max {w.wave_ticks_max*0.01:.1f} us (cumulative)")
+    prays = rays
