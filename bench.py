@@ -122,7 +122,7 @@ def main():
     if rank == 0:
         dev.set_count_work(True)
         dev.render_device(cam, params, frame.data_ptr(), stream=stream, stats=st)
-        work_k = [dev.get_work(0), dev.get_work(1)]
+        work_k = [dev.get_work(k) for k in range(4)]
         work_hits = st.shadow_rays // max(len(fs.lights), 1)      # shaded hits (each shoots one ray per light)
         dev.set_count_work(False)
         ref_frame = frame.clone()
@@ -191,34 +191,40 @@ def main():
         identical = bool(torch.equal(frame, ref_frame))
         out["frame_identical_to_1gpu"] = identical
         if world == 1:
-            # The frame's time is in two kernels: k_extend (closest hits) and k_shade (shadow rays + Phong). A call
-            # with stats runs them back to back on ONE stream with HIP events around every launch (the untimed path
-            # overlaps k_shade with deeper k_extend launches, which would blur per-kernel durations).
+            # The frame's time is in four kernels: k_extend_wide / k_extend_quad (closest hits: analytic objects one ray
+            # per lane, meshes one ray per quad) and k_shade_wide / k_shade_quad (shadow rays + Phong). A call with stats
+            # runs them back to back on ONE stream with HIP events around every launch (the untimed path overlaps the
+            # shade kernels with deeper extend launches, which would blur per-kernel durations).
             reps = 10
-            ms = {"k_extend": 0.0, "k_shade": 0.0}
-            n = {"k_extend": 0, "k_shade": 0}
+            names = ("k_extend_wide", "k_shade_wide", "k_extend_quad", "k_shade_quad")
+            ms = [0.0] * 4
+            n = [0] * 4
             frame_ms = 0.0
             for _ in range(reps):
                 s2 = rt_stats()
                 dev.render_device(cam, params, frame.data_ptr(), stream=stream, stats=s2)
-                ms["k_extend"] += s2.extend_ms; n["k_extend"] += s2.extend_launches
-                ms["k_shade"] += s2.shade_ms; n["k_shade"] += s2.shade_launches
+                for k in range(4):
+                    ms[k] += s2.kernel_ms_by[k]; n[k] += s2.kernel_launches_by[k]
                 frame_ms += s2.kernel_ms
-            hits = work_hits
             per_kernel = {}
-            for ki, name in enumerate(("k_extend", "k_shade")):
+            for ki, name in enumerate(names):
+                if not n[ki]:
+                    continue
                 wk = work_k[ki]
-                rays_k = st.trace_calls if ki == 0 else st.shadow_rays
-                b, f = algorithmic_work(wk, rays_k, hits if ki == 1 else 0, len(fs.lights))
-                lp = n[name] / reps
-                avg = ms[name] / max(n[name], 1)
+                # rays whose record the kernel reads or writes (48 B each in the survey's formula): a wide kernel sees
+                # every ray of its kind, a quad kernel the rays it traverses (16 per batch at most)
+                rays_k = (st.trace_calls if ki in (0, 2) else st.shadow_rays) if ki < 2 else min(16 * wk.batches, st.trace_calls if ki == 2 else st.shadow_rays)
+                b, f = algorithmic_work(wk, rays_k, work_hits if ki == 1 else 0, len(fs.lights))
+                lp = n[ki] / reps
+                avg = ms[ki] / n[ki]
                 per_kernel[name] = {
-                    "avg_launch_ms": avg, "launches_per_frame": lp, "ms_per_frame_serial": ms[name] / reps,
+                    "avg_launch_ms": avg, "launches_per_frame": lp, "ms_per_frame_serial": ms[ki] / reps,
                     "algorithmic_bytes_per_launch": b / lp, "GB/s": b / lp / (avg * 1e-3) / 1e9,
-                    "TFLOP/s": f / lp / (avg * 1e-3) / 1e12, "rays_per_frame": rays_k,
+                    "TFLOP/s": f / lp / (avg * 1e-3) / 1e12,
                     "work_per_frame": {"bvh_nodes": wk.nodes_visited, "tri_tests": wk.tris_tested,
                                        "sphere_tests": wk.spheres_tested, "plane_tests": wk.planes_tested,
-                                       "wave_node_steps": wk.wave_node_steps, "wave_tri_steps": wk.wave_tri_steps}}
+                                       "wave_node_steps": wk.wave_node_steps, "wave_tri_steps": wk.wave_tri_steps,
+                                       "batches": wk.batches}}
             dom = max(per_kernel, key=lambda k: per_kernel[k]["ms_per_frame_serial"])
             d = per_kernel[dom]
             out["roofline"] = {

@@ -42,6 +42,11 @@ struct Builder {
     bool balanced = false;           // median splits only (fallback when the SAH tree needs too much stack)
     Bvh4Node* nodes = nullptr;       // output
     uint32_t n_nodes = 0;
+    std::vector<uint32_t> leaf_first;   // per leaf block: first position in order[], count in the reference
+    uint32_t leaf_block(uint32_t ref2) {   // binary-tree leaf reference (first position) -> block reference
+        leaf_first.push_back(ref2 & RT_LEAF_START_MASK);
+        return (ref2 & ~RT_LEAF_START_MASK) | uint32_t(leaf_first.size() - 1);
+    }
 
     static constexpr int NBINS = 16;
 
@@ -127,18 +132,17 @@ struct Builder {
         }
         const uint32_t idx = n_nodes++;
         uint32_t dmax = 0, smax = 0;
-        Bvh4Child out[4];
+        Bvh4Node out;
         for (int i = 0; i < 4; ++i) {
-            Bvh4Child& c = out[i];
-            c.pad = 0;
-            if (i >= k) { for (int a = 0; a < 3; ++a) { c.lo[a] = INFINITY; c.hi[a] = -INFINITY; } c.ref = RT_NO_CHILD; continue; }
-            pad(cb[i], c.lo, c.hi);
-            if (cr[i] & RT_LEAF_BIT) { c.ref = cr[i]; continue; }
+            out.b[i].pad = 0;
+            if (i >= k) { for (int a = 0; a < 3; ++a) { out.a[i].lo[a] = INFINITY; out.b[i].hi[a] = -INFINITY; } out.a[i].ref = RT_NO_CHILD; continue; }
+            pad(cb[i], out.a[i].lo, out.b[i].hi);
+            if (cr[i] & RT_LEAF_BIT) { out.a[i].ref = leaf_block(cr[i]); continue; }
             uint32_t d = 0, st = 0;
-            c.ref = collapse(cr[i], by_area, d, st);
+            out.a[i].ref = collapse(cr[i], by_area, d, st);
             dmax = std::max(dmax, d); smax = std::max(smax, st);
         }
-        std::memcpy(nodes[idx].c, out, sizeof out);
+        nodes[idx] = out;
         depth = dmax + 1;
         stack = smax + uint32_t(k - 1);
         return idx;
@@ -233,8 +237,7 @@ int bvh_build(const rt_flat_scene* sc, BvhBuildResult* out) {
     }
     out->nodes = static_cast<Bvh4Node*>(std::malloc(sizeof(Bvh4Node) * std::max<size_t>(1, nf)));
     out->model_root = static_cast<uint32_t*>(std::malloc(sizeof(uint32_t) * std::max<uint32_t>(1, sc->n_models)));
-    out->tris = static_cast<TriIsect*>(std::malloc(sizeof(TriIsect) * std::max<size_t>(1, nf)));
-    if (!out->nodes || !out->model_root || !out->tris) { bvh_free(out); return -2; }
+    if (!out->nodes || !out->model_root) { bvh_free(out); return -2; }
     B.nodes = out->nodes;
     B.nodes2.resize(std::max<size_t>(1, nf));
     uint32_t max_depth = 0, max_stack = 0;
@@ -247,6 +250,7 @@ int bvh_build(const rt_flat_scene* sc, BvhBuildResult* out) {
             B.balanced = attempt == 1;
             B.n_nodes2 = 0;
             const uint32_t nodes_before = B.n_nodes;
+            const size_t leaves_before = B.leaf_first.size();
             Box bx;
             uint32_t root2 = 0;
 #pragma omp parallel
@@ -254,7 +258,8 @@ int bvh_build(const rt_flat_scene* sc, BvhBuildResult* out) {
             root2 = B.build(md.first_face, md.first_face + md.num_faces, 0, bx);
             uint32_t depth = 0, stack = 0, root = root2;
             if (!(root2 & RT_LEAF_BIT)) root = B.collapse(root2, !B.balanced, depth, stack);
-            if (stack + 1 > RT_QSTACK && attempt == 0) { B.n_nodes = nodes_before; continue; }
+            else root = B.leaf_block(root2);
+            if (stack + 1 > RT_QSTACK && attempt == 0) { B.n_nodes = nodes_before; B.leaf_first.resize(leaves_before); continue; }
             if (stack + 1 > RT_QSTACK) { bvh_free(out); return -3; }
             out->model_root[m] = root;
             max_depth = std::max(max_depth, depth);
@@ -265,28 +270,40 @@ int bvh_build(const rt_flat_scene* sc, BvhBuildResult* out) {
     out->n_nodes = B.n_nodes;
     out->max_depth = max_depth;
     out->max_stack = max_stack;
-    out->n_tris = nf;
+    // leaf blocks; a block's triangle count is in every reference to it, so the block itself only needs the data
+    // (unused slots are zero: never read, the quad tests lanes j < count only)
+    const size_t nl = B.leaf_first.size();
+    out->leaves = static_cast<LeafBlock*>(std::calloc(std::max<size_t>(1, nl), sizeof(LeafBlock)));
+    if (!out->leaves) { bvh_free(out); return -2; }
+    out->n_leaves = uint32_t(nl);
+    std::vector<uint32_t> leaf_cnt(nl, 0);
+    {   // counts: from the references (nodes and roots)
+        auto note = [&](uint32_t ref) { if (ref != RT_NO_CHILD && (ref & RT_LEAF_BIT)) leaf_cnt[ref & RT_LEAF_START_MASK] = ((ref >> 27) & 15u) + 1u; };
+        for (uint32_t n = 0; n < out->n_nodes; ++n) for (int i = 0; i < 4; ++i) note(out->nodes[n].a[i].ref);
+        for (uint32_t m = 0; m < sc->n_models; ++m) note(out->model_root[m]);
+    }
 #pragma omp parallel for schedule(static)
-    for (uint32_t i = 0; i < nf; ++i) {
-        const uint32_t f = B.order[i];
-        TriIsect& t = out->tris[i];
-        const float* a = sc->v0 + 3 * size_t(f);
-        const float* b = sc->v1 + 3 * size_t(f);
-        const float* c = sc->v2 + 3 * size_t(f);
-        for (int k = 0; k < 3; ++k) {
-            t.v0[k] = a[k];
-            t.e1[k] = b[k] - a[k];   // v0v1, reference src/primitives.cpp:52
-            t.e2[k] = c[k] - a[k];   // v0v2, reference src/primitives.cpp:53
+    for (size_t l = 0; l < nl; ++l) {
+        LeafBlock& lb = out->leaves[l];
+        for (uint32_t j = 0; j < leaf_cnt[l]; ++j) {
+            const uint32_t f = B.order[B.leaf_first[l] + j];
+            const float* a = sc->v0 + 3 * size_t(f);
+            const float* b = sc->v1 + 3 * size_t(f);
+            const float* c = sc->v2 + 3 * size_t(f);
+            for (int k = 0; k < 3; ++k) {
+                lb.a[j].v0[k] = a[k];
+                lb.b[j].e1[k] = b[k] - a[k];   // v0v1, reference src/primitives.cpp:52
+                lb.c[j].e2[k] = c[k] - a[k];   // v0v2, reference src/primitives.cpp:53
+            }
+            lb.a[j].face = f;
         }
-        t.face = f;
-        t.pad1 = t.pad2 = 0;
     }
     return 0;
 }
 
 void bvh_free(BvhBuildResult* r) {
     std::free(r->nodes);
-    std::free(r->tris);
+    std::free(r->leaves);
     std::free(r->model_root);
     std::memset(r, 0, sizeof *r);
 }

@@ -44,16 +44,19 @@ void rt_set_error(const char* fmt, ...) {
 struct PassCounters {                 // one per pass, zeroed by one memset per frame
     uint32_t level[RT_MAX_LEVELS + 4];   // entries appended per level (index 0 unused)
     uint32_t cancel[RT_MAX_LEVELS + 4];  // per level: children of parents that took trace()'s `return red` exit
+    uint32_t qe[RT_MAX_LEVELS + 4];      // per level: rays k_extend_wide queued for k_extend_quad
+    uint32_t qs[RT_MAX_LEVELS + 4];      // per level: hits k_shade_wide queued for k_shade_quad
     uint32_t overflow;
     uint32_t pad[3];
     unsigned long long shadow[RT_STAT_SHARDS];
-    unsigned long long work[RT_WORK_SHARDS][2][12];   // per shard: k_extend, k_shade
+    unsigned long long work[RT_WORK_SHARDS][4][12];   // per shard: RT_K_* kernels
 };
 
 #define RT_MAX_PASSES 1024
 #define RT_PASS_SAMPLES (4u << 20)    // level-0 samples per pass
 #define RT_POOL_FACTOR 6u             // node pool = 6x the pass size when materials bounce (level 0 + 5x for deeper levels)
 #define RT_MAX_TIMED 2048
+enum { RT_K_EXTEND_WIDE = 0, RT_K_SHADE_WIDE = 1, RT_K_EXTEND_QUAD = 2, RT_K_SHADE_QUAD = 3 };
 #define RT_LEVEL_GRID 8192u           // workgroups of a level >= 1 launch (grid-stride over the device-side count)
 
 struct rt_scene {
@@ -73,6 +76,10 @@ struct rt_scene {
     float4* rays = nullptr;
     float4* hit_n = nullptr;
     float4* hit_p = nullptr;
+    uint2* queue_e = nullptr;
+    uint2* queue_s = nullptr;
+    uint32_t* h_hint = nullptr;          // pinned: level sizes of the most recent pass (async copy, read without a sync:
+                                         // only a scheduling hint, results never depend on it)
     PassCounters* d_counters = nullptr;
     PassCounters* h_counters = nullptr;   // pinned
     float* d_aa = nullptr;
@@ -80,7 +87,7 @@ struct rt_scene {
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     std::vector<hipEvent_t> ev_pool;
     bool count_work = false;
-    rt_work last_work[2]{};            // k_extend, k_shade
+    rt_work last_work[4]{};            // RT_K_* kernels
     int last_overflow = 0;
 };
 
@@ -88,8 +95,9 @@ static int free_scene(rt_scene* s) {
     if (!s) return RT_OK;
     hipSetDevice(s->device);
     for (void* p : s->owned) hipFree(p);
-    hipFree(s->node_a); hipFree(s->node_b); hipFree(s->rays); hipFree(s->hit_n); hipFree(s->hit_p); hipFree(s->d_counters); hipFree(s->d_aa); hipFree(s->d_frame);
+    hipFree(s->node_a); hipFree(s->node_b); hipFree(s->rays); hipFree(s->hit_n); hipFree(s->hit_p); hipFree(s->queue_e); hipFree(s->queue_s); hipFree(s->d_counters); hipFree(s->d_aa); hipFree(s->d_frame);
     if (s->h_counters) hipHostFree(s->h_counters);
+    if (s->h_hint) hipHostFree(s->h_hint);
     if (s->ev_begin) hipEventDestroy(s->ev_begin);
     if (s->ev_end) hipEventDestroy(s->ev_end);
     for (hipEvent_t e : s->ev_pool) hipEventDestroy(e);
@@ -198,7 +206,7 @@ extern "C" int rt_scene_create(const rt_flat_scene* sc, int device, rt_scene** o
     if ((rc = upload(s, sc->materials, size_t(sc->n_materials), &s->d.materials)) != RT_OK) return fail(rc);
     if ((rc = upload(s, li.data(), li.size(), &s->d.lights)) != RT_OK) return fail(rc);
     if ((rc = upload(s, bvh.nodes, size_t(bvh.n_nodes), &s->d.nodes)) != RT_OK) return fail(rc);
-    if ((rc = upload(s, bvh.tris, size_t(bvh.n_tris), &s->d.tris)) != RT_OK) return fail(rc);
+    if ((rc = upload(s, bvh.leaves, size_t(bvh.n_leaves), &s->d.leaves)) != RT_OK) return fail(rc);
     if ((rc = upload(s, nrm.data(), nrm.size(), &s->d.normals)) != RT_OK) return fail(rc);
     s->n_models = sc->n_models;
     s->n_faces = sc->n_faces;
@@ -208,12 +216,14 @@ extern "C" int rt_scene_create(const rt_flat_scene* sc, int device, rt_scene** o
 
     if (hipMalloc(reinterpret_cast<void**>(&s->d_counters), sizeof(PassCounters) * RT_MAX_PASSES) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&s->h_counters), sizeof(PassCounters) * RT_MAX_PASSES) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&s->h_hint), sizeof(uint32_t) * (RT_MAX_LEVELS + 4)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&s->d_aa), sizeof(float) * 2 * (RT_MAX_AA_POINTS + 1)) != hipSuccess ||
         hipEventCreate(&s->ev_begin) != hipSuccess || hipEventCreate(&s->ev_end) != hipSuccess) {
         rt_set_error("workspace allocation failed: %s", hipGetErrorString(hipGetLastError()));
         free_scene(s);
         return RT_ERR_DEVICE;
     }
+    for (int i = 0; i < RT_MAX_LEVELS + 4; ++i) s->h_hint[i] = 0xFFFFFFFFu;   // unknown: assume large levels
     *out = s;
     return RT_OK;
 }
@@ -223,7 +233,7 @@ extern "C" void rt_scene_destroy(rt_scene* s) { free_scene(s); }
 extern "C" int rt_scene_bvh_info(const rt_scene* s, rt_bvh_info* out) {
     if (!s || !out) { rt_set_error("null argument"); return RT_ERR_INVALID; }
     out->n_nodes = s->n_nodes; out->n_faces = s->n_faces; out->max_depth = s->bvh_depth;
-    out->node_bytes = sizeof(Bvh4Node); out->tri_bytes = sizeof(TriIsect); out->reserved = 0;
+    out->node_bytes = sizeof(Bvh4Node); out->tri_bytes = sizeof(LeafBlock) / 4; out->reserved = 0;
     out->device_bytes = s->scene_bytes;
     return RT_OK;
 }
@@ -241,15 +251,17 @@ static void add_work(rt_work& w, const unsigned long long* c) {
     w.wave_ticks_sum += c[10]; w.wave_ticks_max = std::max<uint64_t>(w.wave_ticks_max, c[11]);
 }
 extern "C" int rt_get_work(const rt_scene* s, int kernel, rt_work* out) {
-    if (!s || !out || kernel < -1 || kernel > 1) { rt_set_error("bad argument"); return RT_ERR_INVALID; }
+    if (!s || !out || kernel < -1 || kernel > 3) { rt_set_error("bad argument"); return RT_ERR_INVALID; }
     if (kernel >= 0) { *out = s->last_work[kernel]; return RT_OK; }
-    const rt_work &a = s->last_work[0], &b = s->last_work[1];
-    out->nodes_visited = a.nodes_visited + b.nodes_visited; out->tris_tested = a.tris_tested + b.tris_tested;
-    out->spheres_tested = a.spheres_tested + b.spheres_tested; out->planes_tested = a.planes_tested + b.planes_tested;
-    out->wave_node_steps = a.wave_node_steps + b.wave_node_steps; out->wave_tri_steps = a.wave_tri_steps + b.wave_tri_steps;
-    out->trav_ticks_sum = a.trav_ticks_sum + b.trav_ticks_sum; out->trav_ticks_max = std::max(a.trav_ticks_max, b.trav_ticks_max);
-    out->batches = a.batches + b.batches; out->trav_waves = a.trav_waves + b.trav_waves;
-    out->wave_ticks_sum = a.wave_ticks_sum + b.wave_ticks_sum; out->wave_ticks_max = std::max(a.wave_ticks_max, b.wave_ticks_max);
+    *out = rt_work{};
+    for (const rt_work& a : s->last_work) {
+        out->nodes_visited += a.nodes_visited; out->tris_tested += a.tris_tested;
+        out->spheres_tested += a.spheres_tested; out->planes_tested += a.planes_tested;
+        out->wave_node_steps += a.wave_node_steps; out->wave_tri_steps += a.wave_tri_steps;
+        out->trav_ticks_sum += a.trav_ticks_sum; out->trav_ticks_max = std::max(out->trav_ticks_max, a.trav_ticks_max);
+        out->batches += a.batches; out->trav_waves += a.trav_waves;
+        out->wave_ticks_sum += a.wave_ticks_sum; out->wave_ticks_max = std::max(out->wave_ticks_max, a.wave_ticks_max);
+    }
     return RT_OK;
 }
 
@@ -258,14 +270,19 @@ extern "C" int rt_get_work(const rt_scene* s, int kernel, rt_work* out) {
 // ---------------------------------------------------------------------------------------------------------
 static int ensure_workspace(rt_scene* s, uint32_t n0) {
     if (n0 <= s->ws_n0) return RT_OK;
-    hipFree(s->node_a); hipFree(s->node_b); hipFree(s->rays); hipFree(s->hit_n); hipFree(s->hit_p);
-    s->node_a = nullptr; s->node_b = nullptr; s->rays = nullptr; s->hit_n = nullptr; s->hit_p = nullptr; s->ws_n0 = 0; s->pool_cap = 0;
+    hipFree(s->node_a); hipFree(s->node_b); hipFree(s->rays); hipFree(s->hit_n); hipFree(s->hit_p); hipFree(s->queue_e); hipFree(s->queue_s);
+    s->node_a = nullptr; s->node_b = nullptr; s->rays = nullptr; s->hit_n = nullptr; s->hit_p = nullptr;
+    s->queue_e = nullptr; s->queue_s = nullptr; s->ws_n0 = 0; s->pool_cap = 0;
     const uint64_t cap = uint64_t(n0) * (s->has_bounce ? RT_POOL_FACTOR : 1u);
     if (cap > 0xFFFFFFF0ull) { rt_set_error("pass too large"); return RT_ERR_LIMIT; }
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->node_a), cap * sizeof(float4)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->node_b), cap * sizeof(uint4)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->hit_n), cap * sizeof(float4)));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->hit_p), cap * sizeof(float4)));
+    if (s->n_models) {
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->queue_e), cap * sizeof(uint2)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->queue_s), cap * sizeof(uint2)));
+    }
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->rays), std::max<uint64_t>(cap - n0, 1) * 2 * sizeof(float4)));
     s->ws_n0 = n0;
     s->pool_cap = uint32_t(cap);
@@ -299,7 +316,7 @@ struct FrameJob {
     uint8_t* d_out;
     bool timed;              // per-launch events, everything on one stream
     uint32_t n_timed;
-    std::vector<uint8_t> timed_kind;   // 0 extend, 1 shade
+    std::vector<uint8_t> timed_kind;   // RT_K_*
     uint32_t n_pass_used;
 };
 
@@ -324,10 +341,23 @@ static int timed_launch(FrameJob& J, hipStream_t st, uint8_t kind, F&& launch) {
     return RT_OK;
 }
 
+// Is a level (or range) expected to hold enough rays to fill the chip one per lane? Sizes come from the previous
+// pass of this scene (h_hint); unknown = large.
+static bool expect_large(const rt_scene* s, int lo, int hi) {
+    if (lo == 0) return true;
+    for (int l = lo; l <= hi; ++l)
+        if (s->h_hint[l] > 16u * RT_LEVEL_GRID) return true;
+    return false;
+}
+
 // Enqueue the passes covering pixels [px0, px0+npx) of the frame's pixel order, pass_px pixels at a time.
 // Records which PassCounters slot each pass used in `slots` (px0, npx, slot).
 //
-// Schedule of one pass with L bounce levels (E = k_extend, S = k_shade, F = k_fold):
+// One recursion level = closest hits (E) then, independently, the light loop of those hits (S). Each runs either as
+//   Ew + Eq   per-lane kernel that finishes the rays that never reach a mesh and queues the others, then the quad
+//             kernel that resumes the queue (large levels; scenes without meshes run Ew / Sw alone), or
+//   Ef        the quad kernel on all rays of the level (small levels: one launch less on the dependent chain).
+// Schedule of one pass with L bounce levels (F = k_fold):
 //   stream A (the caller's):  E0  E1  E2 ... EL                      | F(L-1) ... F1  resolve
 //   stream B (shade_stream):      S0  S1            S(2..L)          |
 // S never feeds E, so the level-to-level chain on A is one closest-hit traversal per level; the shadow traversals of
@@ -338,6 +368,7 @@ struct PassRec { uint64_t px0; uint32_t npx; uint32_t slot; };
 static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass_px, std::vector<PassRec>& recs) {
     rt_scene* s = J.s;
     const uint32_t spp = J.base.spp;
+    const bool meshes = s->n_models > 0;
     for (uint64_t done = 0; done < npx; done += pass_px) {
         if (J.n_pass_used >= RT_MAX_PASSES) { rt_set_error("frame needs more than %d passes", RT_MAX_PASSES); return RT_ERR_LIMIT; }
         const uint32_t cnt = uint32_t(std::min<uint64_t>(pass_px, npx - done));
@@ -348,6 +379,8 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
         A.sample0 = (px0 + done) * spp;
         A.counters = pc->level;
         A.cancelled = pc->cancel;
+        A.qcount_e = pc->qe;
+        A.qcount_s = pc->qs;
         A.overflow = &pc->overflow;
         A.shadow_count = pc->shadow;
         A.work = &pc->work[0][0][0];
@@ -355,17 +388,9 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
         const bool overlap = !J.timed && levels >= 1;
         hipStream_t sa = J.st, sb = overlap ? s->shade_stream : J.st;
         const uint32_t grid0 = (A.n0 + RT_BLOCK - 1) / RT_BLOCK;
+        const uint32_t grid0q = std::min<uint32_t>((A.n0 + 15) / 16, 4u * RT_LEVEL_GRID);
         int rc;
-        auto shade = [&](int lo, int hi, int ev) -> int {
-            if (overlap) {
-                HIP_TRY(hipEventRecord(s->ev_sync[ev], sa));
-                HIP_TRY(hipStreamWaitEvent(sb, s->ev_sync[ev], 0));
-            }
-            LevelArgs B = A;
-            B.level = lo; B.level_hi = hi;
-            return timed_launch(J, sb, 1, [&] { launch_shade(s->count_work, s->d, B, hi == 0 ? grid0 : RT_LEVEL_GRID, sb); });
-        };
-        // diagnostics: RT_WAVE_LOG=<level>:<file> dumps per-workgroup timing of that level's k_extend (COUNT builds)
+        // diagnostics: RT_WAVE_LOG=<level>:<file> dumps per-workgroup timing of that level's quad extend kernel (COUNT builds)
         uint4* wave_log = nullptr;
         int log_level = -1;
         const char* log_path = nullptr;
@@ -373,23 +398,47 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
             if (const char* e = std::getenv("RT_WAVE_LOG")) {
                 log_level = std::atoi(e);
                 log_path = std::strchr(e, ':');
-                if (log_path) { ++log_path; hipMalloc(reinterpret_cast<void**>(&wave_log), sizeof(uint4) * std::max(grid0, RT_LEVEL_GRID)); }
-                if (wave_log) hipMemsetAsync(wave_log, 0, sizeof(uint4) * std::max(grid0, RT_LEVEL_GRID), sa);
+                if (log_path) { ++log_path; hipMalloc(reinterpret_cast<void**>(&wave_log), sizeof(uint4) * 4u * RT_LEVEL_GRID); }
+                if (wave_log) hipMemsetAsync(wave_log, 0, sizeof(uint4) * 4u * RT_LEVEL_GRID, sa);
             }
         }
+        auto extend = [&](int lv) -> int {
+            LevelArgs B = A;
+            B.level = lv; B.level_hi = lv;
+            const int src = lv == 0 ? 0 : 1;
+            const bool large = !meshes || expect_large(s, lv, lv);
+            if (large) {
+                if ((rc = timed_launch(J, sa, RT_K_EXTEND_WIDE, [&] { launch_extend(src, RT_FORM_WIDE, s->count_work, s->d, B, lv == 0 ? grid0 : RT_LEVEL_GRID, sa); })) != RT_OK) return rc;
+                if (!meshes) return RT_OK;
+            }
+            B.wave_log = (lv == log_level) ? wave_log : nullptr;
+            const uint32_t g = lv == 0 ? grid0q : (large ? 4u * RT_LEVEL_GRID : RT_LEVEL_GRID);
+            return timed_launch(J, sa, RT_K_EXTEND_QUAD, [&] { launch_extend(src, large ? RT_FORM_QUAD_RESUME : RT_FORM_QUAD_FRESH, s->count_work, s->d, B, g, sa); });
+        };
+        auto shade = [&](int lo, int hi, int ev) -> int {
+            if (overlap) {
+                HIP_TRY(hipEventRecord(s->ev_sync[ev], sa));
+                HIP_TRY(hipStreamWaitEvent(sb, s->ev_sync[ev], 0));
+            }
+            LevelArgs B = A;
+            B.level = lo; B.level_hi = hi;
+            const bool large = !meshes || expect_large(s, lo, hi);
+            if (large) {
+                if ((rc = timed_launch(J, sb, RT_K_SHADE_WIDE, [&] { launch_shade(RT_FORM_WIDE, s->count_work, s->d, B, hi == 0 ? grid0 : RT_LEVEL_GRID, sb); })) != RT_OK) return rc;
+                if (!meshes) return RT_OK;
+            }
+            const uint32_t g = hi == 0 ? grid0q : (large ? 4u * RT_LEVEL_GRID : RT_LEVEL_GRID);
+            return timed_launch(J, sb, RT_K_SHADE_QUAD, [&] { launch_shade(large ? RT_FORM_QUAD_RESUME : RT_FORM_QUAD_FRESH, s->count_work, s->d, B, g, sb); });
+        };
         for (int lv = 0; lv <= levels; ++lv) {
-            A.level = lv; A.level_hi = lv;
-            A.wave_log = (lv == log_level) ? wave_log : nullptr;
-            if ((rc = timed_launch(J, sa, 0, [&] { launch_extend(lv == 0 ? 0 : 1, s->count_work, s->d, A, lv == 0 ? grid0 : RT_LEVEL_GRID, sa); })) != RT_OK) return rc;
+            if ((rc = extend(lv)) != RT_OK) return rc;
             if (lv <= 1 && (rc = shade(lv, lv, lv)) != RT_OK) return rc;
         }
-        A.wave_log = nullptr;
         if (wave_log) {
-            const uint32_t n = (log_level == 0) ? grid0 : RT_LEVEL_GRID;
-            std::vector<uint4> h(n);
+            std::vector<uint4> h(4u * RT_LEVEL_GRID);
             hipStreamSynchronize(sa);
-            hipMemcpy(h.data(), wave_log, sizeof(uint4) * n, hipMemcpyDeviceToHost);
-            if (FILE* f = std::fopen(log_path, "wb")) { std::fwrite(h.data(), sizeof(uint4), n, f); std::fclose(f); }
+            hipMemcpy(h.data(), wave_log, sizeof(uint4) * h.size(), hipMemcpyDeviceToHost);
+            if (FILE* f = std::fopen(log_path, "wb")) { std::fwrite(h.data(), sizeof(uint4), h.size(), f); std::fclose(f); }
             hipFree(wave_log);
         }
         if (levels >= 2 && (rc = shade(2, levels, 2)) != RT_OK) return rc;
@@ -404,6 +453,8 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
         A.level = 0; A.level_hi = 0;
         launch_resolve(s->d, A, J.d_out, sa);
         HIP_TRY(hipGetLastError());
+        // level sizes of this pass -> scheduling hint of the next one (no sync; see h_hint)
+        HIP_TRY(hipMemcpyAsync(s->h_hint, pc->level, sizeof(uint32_t) * (RT_MAX_LEVELS + 4), hipMemcpyDeviceToHost, sa));
         recs.push_back({px0 + done, cnt, slot});
     }
     return RT_OK;
@@ -429,7 +480,7 @@ static int render_frame(rt_scene* s, const rt_camera* cam, const rt_params* prm,
     B.spp = spp;
     B.pool_cap = s->pool_cap;
     if (const char* dbg = std::getenv("RT_DEBUG_SKIP")) { B.debug = uint32_t(std::atoi(dbg)); s->d.debug = B.debug; }   // timing experiments only
-    B.rays = s->rays; B.node_a = s->node_a; B.node_b = s->node_b; B.hit_n = s->hit_n; B.hit_p = s->hit_p;
+    B.rays = s->rays; B.node_a = s->node_a; B.node_b = s->node_b; B.hit_n = s->hit_n; B.hit_p = s->hit_p; B.queue_e = s->queue_e; B.queue_s = s->queue_s;
     B.aa = s->d_aa;
     std::memcpy(B.background, prm->background, sizeof B.background);
     B.pm = pm;
@@ -475,15 +526,15 @@ static int render_frame(rt_scene* s, const rt_camera* cam, const rt_params* prm,
     if (stats) {
         HIP_TRY(hipEventRecord(s->ev_end, st));
         HIP_TRY(hipStreamSynchronize(st));
-        rt_work w[2]{};
+        rt_work w[4]{};
         for (const PassRec& r : final_recs) {
             const PassCounters& pc = s->h_counters[r.slot];
             // level 0: every valid sample is one trace() call; deeper levels: appended entries
             for (int k = 0; k < RT_STAT_SHARDS; ++k) stats->shadow_rays += pc.shadow[k];
             for (int lv = 1; lv < RT_MAX_LEVELS; ++lv) stats->level_rays[lv] += pc.level[lv] - pc.cancel[lv];
-            for (int sh = 0; sh < RT_WORK_SHARDS; ++sh) { add_work(w[0], pc.work[sh][0]); add_work(w[1], pc.work[sh][1]); }
+            for (int sh = 0; sh < RT_WORK_SHARDS; ++sh) for (int k = 0; k < 4; ++k) add_work(w[k], pc.work[sh][k]);
         }
-        s->last_work[0] = w[0]; s->last_work[1] = w[1];
+        for (int k = 0; k < 4; ++k) s->last_work[k] = w[k];
         stats->passes = uint32_t(final_recs.size());
         stats->retries = retries;
         float ms = 0;
@@ -492,8 +543,8 @@ static int render_frame(rt_scene* s, const rt_camera* cam, const rt_params* prm,
         for (uint32_t i = 0; i < J.n_timed; ++i) {
             float t = 0;
             HIP_TRY(hipEventElapsedTime(&t, s->ev_pool[2 * i], s->ev_pool[2 * i + 1]));
-            if (J.timed_kind[i] == 0) { stats->extend_ms += t; stats->extend_launches += 1; }
-            else { stats->shade_ms += t; stats->shade_launches += 1; }
+            stats->kernel_ms_by[J.timed_kind[i]] += t;
+            stats->kernel_launches_by[J.timed_kind[i]] += 1;
         }
     }
     return RT_OK;
@@ -684,21 +735,28 @@ static int trace_chunk(rt_scene* s, const rt_params* prm, const float* d_rays, u
     std::memset(&A, 0, sizeof A);
     A.n0 = n; A.max_depth = prm->max_depth; A.spp = 1;
     A.counters = s->d_counters->level; A.cancelled = s->d_counters->cancel; A.overflow = &s->d_counters->overflow;
+    A.qcount_e = s->d_counters->qe; A.qcount_s = s->d_counters->qs;
     A.shadow_count = s->d_counters->shadow;
     A.work = &s->d_counters->work[0][0][0];
     A.node_a = s->node_a; A.node_b = s->node_b; A.hit_n = s->hit_n; A.hit_p = s->hit_p; A.user_rays = d_rays;
+    A.queue_e = s->queue_e; A.queue_s = s->queue_s;
     // pool entry i >= n0 keeps its ray at rays[2*(i-n0)]; the ray array holds pool_cap - ws_n0 entries, so with
     // n0 = n <= ws_n0 the usable pool shrinks accordingly
     A.rays = s->rays;
     A.pool_cap = s->pool_cap - (s->ws_n0 - n);
     std::memcpy(A.background, prm->background, sizeof A.background);
     const int levels = s->has_bounce ? A.max_depth : 0;
+    const bool meshes = s->n_models > 0;
+    const uint32_t gq = std::min<uint32_t>((n + 15) / 16, 4u * RT_LEVEL_GRID);
+    // per-lane kernels + resumed queues at every level (level sizes are unknown here), one shade pass over all levels
     for (int lv = 0; lv <= levels; ++lv) {
         A.level = lv; A.level_hi = lv;
-        launch_extend(lv == 0 ? 2 : 1, s->count_work, s->d, A, lv == 0 ? (n + RT_BLOCK - 1) / RT_BLOCK : RT_LEVEL_GRID, st);
+        launch_extend(lv == 0 ? 2 : 1, RT_FORM_WIDE, s->count_work, s->d, A, lv == 0 ? (n + RT_BLOCK - 1) / RT_BLOCK : RT_LEVEL_GRID, st);
+        if (meshes) launch_extend(lv == 0 ? 2 : 1, RT_FORM_QUAD_RESUME, s->count_work, s->d, A, lv == 0 ? gq : 4u * RT_LEVEL_GRID, st);
     }
-    A.level = 0; A.level_hi = levels;          // one shade launch over the hits of all levels
-    launch_shade(s->count_work, s->d, A, std::max<uint32_t>((n + RT_BLOCK - 1) / RT_BLOCK, levels ? RT_LEVEL_GRID : 1u), st);
+    A.level = 0; A.level_hi = levels;
+    launch_shade(RT_FORM_WIDE, s->count_work, s->d, A, std::max<uint32_t>((n + RT_BLOCK - 1) / RT_BLOCK, levels ? RT_LEVEL_GRID : 1u), st);
+    if (meshes) launch_shade(RT_FORM_QUAD_RESUME, s->count_work, s->d, A, 4u * RT_LEVEL_GRID, st);
     for (int lv = levels - 1; lv >= 1; --lv) { A.level = lv; A.level_hi = lv; launch_fold(s->d, A, 1024, st); }
     A.level = 0; A.level_hi = 0;
     launch_resolve_rgb(s->d, A, d_rgb, st);
@@ -712,7 +770,7 @@ static int trace_chunk(rt_scene* s, const rt_params* prm, const float* d_rays, u
         for (int lv = 1; lv < RT_MAX_LEVELS; ++lv) stats->level_rays[lv] += pc.level[lv] - pc.cancel[lv];
         for (int k = 0; k < RT_STAT_SHARDS; ++k) stats->shadow_rays += pc.shadow[k];
         stats->passes += 1;
-        for (int sh = 0; sh < RT_WORK_SHARDS; ++sh) { add_work(s->last_work[0], pc.work[sh][0]); add_work(s->last_work[1], pc.work[sh][1]); }
+        for (int sh = 0; sh < RT_WORK_SHARDS; ++sh) for (int k = 0; k < 4; ++k) add_work(s->last_work[k], pc.work[sh][k]);
     }
     return RT_OK;
 }
@@ -729,7 +787,7 @@ extern "C" int rt_trace(rt_scene* s, const rt_params* prm, const float* rays, ui
     DevBuf dr, dout;
     if (dr.alloc(sizeof(float) * 6 * size_t(n)) || dout.alloc(sizeof(float) * 3 * size_t(n))) { rt_set_error("hipMalloc failed"); return RT_ERR_DEVICE; }
     HIP_TRY(hipMemcpy(dr.p, rays, sizeof(float) * 6 * size_t(n), hipMemcpyHostToDevice));
-    s->last_work[0] = rt_work{}; s->last_work[1] = rt_work{};
+    for (rt_work& w : s->last_work) w = rt_work{};
     for (uint32_t done = 0; done < n;) {
         const uint32_t cnt = std::min(chunk, n - done);
         bool overflow = false;

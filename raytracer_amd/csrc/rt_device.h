@@ -9,13 +9,14 @@
 // A ray is traversed by a QUAD of lanes: lane j of the quad fetches child j (two 16-B loads, the quad's 8 loads cover
 // exactly this line), tests its box, and the quad orders the hit children with cross-lane moves. Leaves hold up to 4
 // triangles, one per lane of the quad. Child reference: bit 31 clear -> index of another Bvh4Node; bit 31 set -> leaf:
-//   bits 0..26 = first triangle (index into the leaf-ordered triangle array), bits 27..30 = count-1.
+//   bits 0..26 = leaf block index, bits 27..30 = triangle count-1.
 // Unused child slots have ref = RT_NO_CHILD.
-struct Bvh4Child {
-    float lo[3]; uint32_t ref;
-    float hi[3]; uint32_t pad;
+// Layout inside the node: the four {lo, ref} quarters first, then the four {hi, pad} quarters, so that each of the
+// quad's two 16-B loads reads 64 CONTIGUOUS bytes (lane j at +16j and +64+16j): one fully coalesced request per quad.
+struct Bvh4Node {
+    struct { float lo[3]; uint32_t ref; } a[4];
+    struct { float hi[3]; uint32_t pad; } b[4];
 };
-struct Bvh4Node { Bvh4Child c[4]; };
 static_assert(sizeof(Bvh4Node) == 128, "Bvh4Node must be 128 bytes");
 
 #define RT_LEAF_BIT 0x80000000u
@@ -25,15 +26,17 @@ static_assert(sizeof(Bvh4Node) == 128, "Bvh4Node must be 128 bytes");
 #define RT_QSTACK 64             // traversal stack entries per ray (LDS); the builder guarantees the tree never needs more
 #define RT_NO_CHILD 0xFFFFFFFFu
 
-// ---- leaf-ordered triangle record for intersection, 48 B: v0 + original face index, e1 = v1-v0, e2 = v2-v0 ----
+// ---- leaf block, 192 B: the (up to) 4 triangles of one leaf, laid out like a node: four {v0, face} quarters, four
+// e1 quarters, four e2 quarters (e1 = v1-v0, e2 = v2-v0). Lane j of the quad tests triangle j with three 16-B loads,
+// each contiguous over the quad. A leaf reference holds the BLOCK index. ----
 // e1/e2 are the float differences Triangle::intersect forms on every call (reference src/primitives.cpp:52-53);
 // forming them once on the host gives the same bits.
-struct TriIsect {
-    float v0[3]; uint32_t face;   // face = index into the ORIGINAL face arrays (tie-break + normals)
-    float e1[3]; float pad1;
-    float e2[3]; float pad2;
+struct LeafBlock {
+    struct { float v0[3]; uint32_t face; } a[4];   // face = index into the ORIGINAL face arrays (tie-break + normals)
+    struct { float e1[3]; float pad; } b[4];
+    struct { float e2[3]; float pad; } c[4];
 };
-static_assert(sizeof(TriIsect) == 48, "TriIsect must be 48 bytes");
+static_assert(sizeof(LeafBlock) == 192, "LeafBlock must be 192 bytes");
 
 // ---- per-face vertex normals in ORIGINAL face order, 48 B, fetched once per closest hit ----
 struct TriNormals {
@@ -55,7 +58,7 @@ static_assert(sizeof(DModel) == 32, "DModel must be 32 bytes");
 // Host-side result of the BVH build for all models of a scene.
 struct BvhBuildResult {
     Bvh4Node* nodes;       uint32_t n_nodes;
-    TriIsect* tris;        uint32_t n_tris;     // leaf order
+    LeafBlock* leaves;     uint32_t n_leaves;
     uint32_t* model_root;                       // per model
     uint32_t max_depth;                         // interior nodes on the longest root-to-leaf path
     uint32_t max_stack;                         // worst-case traversal stack entries (incl. the sentinel)

@@ -22,6 +22,7 @@
 // exactly where the reference's overload resolution computes in double (sphere roots, pow, camera tan product).
 #include <hip/hip_runtime.h>
 #include <float.h>
+#include <stdlib.h>
 #include <stdint.h>
 
 #include "rt_device.h"
@@ -239,8 +240,8 @@ __device__ __forceinline__ void quad_traverse(const DScene& S, uint32_t root, bo
     uint32_t cur = have ? root : RT_DONE;      // RT_NO_CHILD == RT_DONE for an empty model
     while (cur != RT_DONE) {
         while (!(cur & RT_LEAF_BIT)) {
-            const float4* np = reinterpret_cast<const float4*>(S.nodes + cur) + 2 * j;
-            const float4 a = np[0], b = np[1];
+            const float4* np = reinterpret_cast<const float4*>(S.nodes + cur) + j;
+            const float4 a = np[0], b = np[4];
             if (COUNT) { wk.nodes += (j == 0); wk.wave_nodes += wave_once(); }
             const uint32_t ref = __float_as_uint(a.w);
             bool h;
@@ -267,8 +268,8 @@ __device__ __forceinline__ void quad_traverse(const DScene& S, uint32_t root, bo
             if (COUNT) { wk.tris += (j < cnt); wk.wave_tris += wave_once(); }
             bool got = false;
             if (j < cnt) {
-                const float4* tp = reinterpret_cast<const float4*>(S.tris + (start + j));
-                const float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+                const float4* tp = reinterpret_cast<const float4*>(S.leaves + start) + j;
+                const float4 q0 = tp[0], q1 = tp[4], q2 = tp[8];
                 float t, u, v;
                 if (tri_isect(f4xyz(q0), f4xyz(q1), f4xyz(q2), ray, t, u, v)) {
                     const uint32_t f = __float_as_uint(q0.w);
@@ -302,160 +303,128 @@ __device__ __forceinline__ void quad_traverse(const DScene& S, uint32_t root, bo
     out.t = best; out.u = bu; out.v = bv; out.face = face;
 }
 
-// Serves the clients in `need` (wave-wide, convergent): each gets the QuadHit of its ray against the tree under root.
-template <bool ANY, bool COUNT>
-__device__ __forceinline__ QuadHit wave_traverse(const DScene& S, uint32_t root, bool need, const Ray& ray, float tmax,
-                                                 uint32_t* lds_stack, Work& wk) {
-    QuadHit res;
-    res.t = FLT_MAX; res.u = 0; res.v = 0; res.face = 0xFFFFFFFFu;
-    const unsigned long long mask = __ballot(need);
-    if (mask == 0) return res;
-    const uint32_t lane = lane_id();
-    const int n_need = __popcll(mask);
-    const int rank = __popcll(mask & ((1ull << lane) - 1ull));
-    uint32_t* qs = lds_stack + (lane >> 2);
-    unsigned long long c0 = 0;
-    if (COUNT) c0 = wall_clock64();
-    for (int b0 = 0; b0 < n_need; b0 += 16) {
-        if (COUNT) wk.batches++;
-        // client -> quad: the client of rank b0+q tells lane 4q (the quad's first lane) who it is; everybody else
-        // writes to an odd lane, which nobody reads
-        const bool mine = need && rank >= b0 && rank < b0 + 16;
-        const int dest = mine ? 4 * (rank - b0) : (int)(lane | 1u);
-        const uint32_t told = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)(lane + 1u));
-        const uint32_t client1 = dpp_u<QP_BCAST(0)>(told);          // client lane + 1, or 0: idle quad
-        const bool have = client1 != 0u;
-        const int src = (int)((have ? client1 - 1u : lane) << 2);
-        Ray qr;
-        qr.o.x = __uint_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_uint(ray.o.x)));
-        qr.o.y = __uint_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_uint(ray.o.y)));
-        qr.o.z = __uint_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_uint(ray.o.z)));
-        qr.d.x = __uint_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_uint(ray.d.x)));
-        qr.d.y = __uint_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_uint(ray.d.y)));
-        qr.d.z = __uint_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_uint(ray.d.z)));
-        float qmax = FLT_MAX;
-        if (ANY) qmax = __uint_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_uint(tmax)));
-        QuadHit qh;
-        quad_traverse<ANY, COUNT>(S, root, have, qr, qmax, qh, qs, wk);
-        // quad -> client
-        const int back = (mine ? 4 * (rank - b0) : (int)lane) << 2;
-        const uint32_t f = (uint32_t)__builtin_amdgcn_ds_bpermute(back, (int)qh.face);
-        if (ANY) {
-            if (mine) res.face = f;
-        } else {
-            const float t = __uint_as_float(__builtin_amdgcn_ds_bpermute(back, __float_as_uint(qh.t)));
-            const float u = __uint_as_float(__builtin_amdgcn_ds_bpermute(back, __float_as_uint(qh.u)));
-            const float v = __uint_as_float(__builtin_amdgcn_ds_bpermute(back, __float_as_uint(qh.v)));
-            if (mine) { res.t = t; res.u = u; res.v = v; res.face = f; }
-        }
-    }
-    if (COUNT) wk.trav_ticks += wall_clock64() - c0;
-    return res;
-}
-
-// Model::intersect (reference src/primitives.cpp:364-384): dist = FLT_MAX, bounding-sphere gate, closest face,
-// normal = (1-u-v)*n0 + u*n1 + v*n2 (primitives.cpp:80, not normalised). Convergent: every lane of the wave calls it,
-// `alive` says whether the lane has a ray; dist/normal are touched only for alive lanes.
-template <bool COUNT>
-__device__ __forceinline__ bool model_closest(const DScene& S, const ModelRef& m, const Ray& ray, bool alive, float& dist,
-                                              V3& normal, uint32_t* lds_stack, Work& wk) {
-    bool need = alive;
-    if (alive) dist = FLT_MAX;
-    if (m.bb.w >= 0) {
-        if (COUNT) wk.spheres += alive;
-        need = alive && sphere_gate(m.bb, ray);
-    }
-    const QuadHit h = wave_traverse<false, COUNT>(S, m.root, need, ray, FLT_MAX, lds_stack, wk);
-    const bool got = need && h.face != 0xFFFFFFFFu;
-    if (got) {
-        const float4* np = reinterpret_cast<const float4*>(S.normals + h.face);
-        const V3 n0 = f4xyz(np[0]), n1 = f4xyz(np[1]), n2 = f4xyz(np[2]);
-        dist = h.t;
-        normal = (n0 * (1 - h.u - h.v) + n1 * h.u) + n2 * h.v;
-    }
-    return got;   // every accepted face already satisfied dist > EPS
-}
-template <bool COUNT>
-__device__ __forceinline__ bool model_any(const DScene& S, const ModelRef& m, const Ray& ray, bool alive, float tmax,
-                                          uint32_t* lds_stack, Work& wk) {
-    bool need = alive;
-    if (m.bb.w >= 0) {
-        if (COUNT) wk.spheres += alive;
-        need = alive && sphere_gate(m.bb, ray);
-    }
-    const QuadHit h = wave_traverse<true, COUNT>(S, m.root, need, ray, tmax, lds_stack, wk);
-    return need && h.face != 0xFFFFFFFFu;
-}
-
-// Closest-hit loop of trace() (reference src/raytracer.cpp:292-300): objects in scene order, strict <.
+// ---------------------------------------------------------------------------------------------------------
+// The two object loops of trace(), each in two forms:
+//   QUAD = false  one ray per lane (64 per wave). Spheres and planes are tested in place; a ray that passes a mesh's
+//                 bounding-sphere gate SUSPENDS at that object: the loop reports the object index and the caller
+//                 saves the ray's state and queues it for the quad form.
+//   QUAD = true   one ray per quad (16 per wave; the four lanes hold the same values and compute the sphere / plane
+//                 tests redundantly). Meshes are traversed in place. Starts at object k0, so it can resume a
+//                 suspended ray (or run a whole ray with k0 = 0).
+// A wave that carries its 64 rays through a mesh itself would need four 16-ray batches one after the other; queueing
+// them makes those batches independent waves, so the longest dependent chain on the chip is ONE batch.
 // Object table entry k = two uint4: {type, index, material, sphere 1/r bits} and the float4 parameters of a sphere
-// (cx cy cz r) or plane (a b c d). The index k is wave-uniform, so both come in by scalar loads; the next entry is
-// requested before the current one is worked on. Convergent: all 64 lanes call it, `alive` marks lanes with a ray.
-template <bool COUNT>
-__device__ __forceinline__ int closest_hit(const DScene& S, const Ray& ray, bool alive, float& dist, V3& hitNormal,
-                                           float& tmpdist, uint32_t& material, uint32_t* lds_stack, Work& wk) {
-    dist = FLT_MAX;
-    int cur = -1;
-    material = 0;
+// (cx cy cz r) or plane (a b c d). k is wave-uniform, so both come in by scalar loads; the next entry is requested
+// before the current one is worked on.
+// ---------------------------------------------------------------------------------------------------------
+struct HitState { float dist; V3 n; int cur; uint32_t mat; float tmpdist; };
+
+// Closest-hit loop (reference src/raytracer.cpp:292-300): objects in scene order, strict <. Returns -1 when the loop
+// ran to its end, else (QUAD = false only) the index of the mesh object the ray suspended at, with `h` as it was
+// before that object.
+template <bool QUAD, bool COUNT>
+__device__ __forceinline__ int closest_loop(const DScene& S, const Ray& ray, bool alive, uint32_t k0, HitState& h,
+                                            uint32_t* qs, Work& wk) {
+    int susp = -1;
     V3 tmpnormal = mk(0, 0, 0);
-    if (S.n_objects == 0) return cur;
+    if (S.n_objects == 0) return susp;
+    const bool counter = !QUAD || (lane_id() & 3u) == 0;
     u32x4 ob = ldc4(S.objects, 0), pb = ldc4(S.objects, 1);
     for (uint32_t k = 0; k < S.n_objects; ++k) {
         const uint32_t kn = k + 1 < S.n_objects ? k + 1 : k;
         const u32x4 ob_n = ldc4(S.objects, 2 * kn), pb_n = ldc4(S.objects, 2 * kn + 1);
         const float4 prm = as_f4(pb);
+        const bool go = alive && k >= k0 && susp < 0;
         bool hit = false;
         if (ob.x == RT_OBJ_SPHERE) {
-            if (COUNT) wk.spheres += alive;
-            if (alive && !(S.debug & 16u)) hit = sphere_isect(prm, __uint_as_float(ob.w), ray, tmpdist, tmpnormal);
+            if (COUNT) wk.spheres += go && counter;
+            if (go && !(S.debug & 16u)) hit = sphere_isect(prm, __uint_as_float(ob.w), ray, h.tmpdist, tmpnormal);
         } else if (ob.x == RT_OBJ_PLANE) {
-            if (COUNT) wk.planes += alive;
-            if (alive && !(S.debug & 16u)) hit = plane_isect(prm, ray, tmpdist, tmpnormal);
+            if (COUNT) wk.planes += go && counter;
+            if (go && !(S.debug & 16u)) hit = plane_isect(prm, ray, h.tmpdist, tmpnormal);
         } else {
-            hit = model_closest<COUNT>(S, load_model(S.models, ob.y), ray, alive && !(S.debug & 8u), tmpdist, tmpnormal, lds_stack, wk);
+            // Model::intersect (reference src/primitives.cpp:364-384): dist = FLT_MAX, bounding-sphere gate, closest
+            // face, normal = (1-u-v)*n0 + u*n1 + v*n2 (primitives.cpp:80, not normalised)
+            const ModelRef m = load_model(S.models, ob.y);
+            bool need = go && !(S.debug & 8u);
+            if (m.bb.w >= 0) {
+                if (COUNT) wk.spheres += need && counter;
+                need = need && sphere_gate(m.bb, ray);
+            }
+            if (!QUAD) {
+                if (need) susp = (int)k;
+                else if (go) h.tmpdist = FLT_MAX;
+            } else {
+                if (go) h.tmpdist = FLT_MAX;
+                if (need) {
+                    QuadHit q;
+                    quad_traverse<false, COUNT>(S, m.root, true, ray, FLT_MAX, q, qs, wk);
+                    if (q.face != 0xFFFFFFFFu) {
+                        const float4* np = reinterpret_cast<const float4*>(S.normals + q.face);
+                        const V3 n0 = f4xyz(np[0]), n1 = f4xyz(np[1]), n2 = f4xyz(np[2]);
+                        h.tmpdist = q.t;
+                        tmpnormal = (n0 * (1 - q.u - q.v) + n1 * q.u) + n2 * q.v;
+                        hit = true;   // every accepted face already satisfied dist > EPS
+                    }
+                }
+            }
         }
-        if (hit && tmpdist < dist) {
-            dist = tmpdist;
-            hitNormal = tmpnormal;
-            cur = (int)k;
-            material = ob.z;
+        if (hit && h.tmpdist < h.dist) {
+            h.dist = h.tmpdist;
+            h.n = tmpnormal;
+            h.cur = (int)k;
+            h.mat = ob.z;
         }
         ob = ob_n; pb = pb_n;
     }
-    return cur;
+    return susp;
 }
 
-// Shadow loop of trace() (reference src/raytracer.cpp:319-325): any object with hit && tmpdist < ldist; the loop
-// breaks at the first one, so later objects no longer touch tmpdist. Convergent like closest_hit.
-template <bool COUNT>
-__device__ __forceinline__ bool occluded(const DScene& S, const Ray& ray, bool alive, float ldist, float& tmpdist,
-                                         uint32_t* lds_stack, Work& wk) {
+// Shadow loop (reference src/raytracer.cpp:319-325): any object with hit && tmpdist < ldist; the loop breaks at the
+// first one, so later objects no longer touch tmpdist. `susp` as in closest_loop.
+template <bool QUAD, bool COUNT>
+__device__ __forceinline__ bool occluded_loop(const DScene& S, const Ray& ray, bool alive, uint32_t k0, float ldist,
+                                              float& tmpdist, int& susp, uint32_t* qs, Work& wk) {
     V3 tmpnormal;
     bool in = false;
+    susp = -1;
     if (S.n_objects == 0) return in;
+    const bool counter = !QUAD || (lane_id() & 3u) == 0;
     u32x4 ob = ldc4(S.objects, 0), pb = ldc4(S.objects, 1);
     for (uint32_t k = 0; k < S.n_objects; ++k) {
         const uint32_t kn = k + 1 < S.n_objects ? k + 1 : k;
         const u32x4 ob_n = ldc4(S.objects, 2 * kn), pb_n = ldc4(S.objects, 2 * kn + 1);
         const float4 prm = as_f4(pb);
-        const bool go = alive && !in;
+        const bool go = alive && k >= k0 && !in && susp < 0;
         if (ob.x == RT_OBJ_SPHERE) {
-            if (COUNT) wk.spheres += go;
+            if (COUNT) wk.spheres += go && counter;
             if (go) {
                 const bool hit = sphere_isect(prm, __uint_as_float(ob.w), ray, tmpdist, tmpnormal);
                 in = hit && tmpdist < ldist;
             }
         } else if (ob.x == RT_OBJ_PLANE) {
-            if (COUNT) wk.planes += go;
+            if (COUNT) wk.planes += go && counter;
             if (go) {
                 const bool hit = plane_isect(prm, ray, tmpdist, tmpnormal);
                 in = hit && tmpdist < ldist;
             }
         } else {
-            const bool any = model_any<COUNT>(S, load_model(S.models, ob.y), ray, go, ldist, lds_stack, wk);
-            if (go) {
-                in = any;
-                if (!in) tmpdist = FLT_MAX;   // Model::intersect leaves FLT_MAX in dist on a miss (primitives.cpp:368)
+            const ModelRef m = load_model(S.models, ob.y);
+            bool need = go;
+            if (m.bb.w >= 0) {
+                if (COUNT) wk.spheres += need && counter;
+                need = need && sphere_gate(m.bb, ray);
+            }
+            if (!QUAD) {
+                if (need) susp = (int)k;
+                else if (go) tmpdist = FLT_MAX;   // Model::intersect leaves FLT_MAX in dist on a miss (primitives.cpp:368)
+            } else {
+                if (need) {
+                    QuadHit q;
+                    quad_traverse<true, COUNT>(S, m.root, true, ray, ldist, q, qs, wk);
+                    in = q.face != 0xFFFFFFFFu;
+                }
+                if (go && !in) tmpdist = FLT_MAX;
             }
         }
         ob = ob_n; pb = pb_n;
@@ -595,7 +564,7 @@ __device__ __forceinline__ uint32_t rays_per_wave(uint32_t n_items) {
 }
 
 __device__ __forceinline__ void flush_work(unsigned long long* work, uint32_t kernel, const Work& wk) {
-    unsigned long long* out = work + ((blockIdx.x & (RT_WORK_SHARDS - 1)) * 2 + kernel) * 12;   // sharded like shadow_count
+    unsigned long long* out = work + ((blockIdx.x & (RT_WORK_SHARDS - 1)) * 4 + kernel) * 12;   // sharded like shadow_count
     const uint32_t a = wave_sum(wk.nodes), b = wave_sum(wk.tris), c = wave_sum(wk.spheres), d = wave_sum(wk.planes);
     const uint32_t e = wave_sum(wk.wave_nodes), f = wave_sum(wk.wave_tris);
     if (lane_id() == 0) {
@@ -615,10 +584,127 @@ __device__ __forceinline__ void flush_work(unsigned long long* work, uint32_t ke
     }
 }
 
-template <int SRC, bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) void k_extend(DScene S, LevelArgs A) {
-    __shared__ uint32_t lds_stack[RT_QSTACK * 16];
+// The ray of pool entry i (level range starts at `begin`). Returns false for a padding sample outside the image.
+template <int SRC>
+__device__ __forceinline__ bool fetch_ray(const LevelArgs& A, uint32_t begin, uint32_t i, Ray& ray) {
+    if (SRC == 0) {
+        const uint64_t g = A.sample0 + (i - begin);
+        uint32_t x, y; uint64_t off; bool inb;
+        if (!map_pixel(A.pm, g / A.spp, x, y, off, inb)) return false;
+        ray = cast_ray(A.cam, A.aa, x, y, (uint32_t)(g % A.spp));
+    } else if (SRC == 1) {
+        const float4 o = A.rays[2 * (size_t)(i - A.n0)], d = A.rays[2 * (size_t)(i - A.n0) + 1];
+        ray.o = f4xyz(o); ray.d = f4xyz(d);
+    } else {
+        const float* p = A.user_rays + 6 * (size_t)i;
+        ray.o = ld3(p); ray.d = ld3(p + 3);
+    }
+    return true;
+}
 
+// What trace() does with the closest hit apart from the light loop: Fresnel term and child rays
+// (reference src/raytracer.cpp:302-308, 347-396), the node record and the hit record for k_shade.
+// active: this lane / quad holds pool entry i; valid: the entry has a ray; writer: the lane that stores (all lanes in
+// the per-lane kernels, lane 0 of the quad in the quad kernels). Called with the whole wave converged.
+__device__ __forceinline__ void extend_finish(const DScene& S, const LevelArgs& A, uint32_t i, bool active, bool valid,
+                                              bool writer, const Ray& ray, const HitState& h, uint32_t next_base,
+                                              uint32_t* next_count) {
+    uint4 rec_b = make_uint4(RT_NO_CHILD, RT_NO_CHILD, 0, 0);
+    bool want_refl = false, want_refr = false;
+    Ray r_refl, r_refr;
+    r_refl.o = r_refl.d = r_refr.o = r_refr.d = mk(0, 0, 0);
+    V3 hitPt = mk(0, 0, 0);
+    float rCoef = 0;
+    const int cur = (A.debug & 4u) ? -1 : h.cur;
+    if (valid) {
+        rec_b.w = NODE_VALID;
+        if (cur >= 0) {
+            const rt_material* mp = S.materials + h.mat;
+            const float refractiveIdx = mp->refractiveIdx;
+            const bool reflective = mp->reflective != 0, refractive = mp->refractive != 0;
+            const float bias = 0.0001f;                                                  // raytracer.cpp:286
+            hitPt = ray_point(ray, h.dist);
+            const int depth = A.level + 1;                                               // raytracer.cpp:347
+            V3 refractNormal = h.n;
+            float cosI = 0, cosT = 0, sinSqrPhit = 0, n1 = 0, n2 = 0, n = 0;
+            if (refractive && depth <= A.max_depth) {                                    // raytracer.cpp:357-381
+                cosI = dot(ray.d, h.n);
+                if (cosI < 0.0f) { n1 = 1.0f; n2 = refractiveIdx; cosI = -cosI; }
+                else { n1 = refractiveIdx; n2 = 1.0f; refractNormal = neg(refractNormal); }
+                n = n1 / n2;
+                sinSqrPhit = n * n * (1 - cosI * cosI);
+                if (sinSqrPhit <= 1) {
+                    cosT = sqrtf(1 - sinSqrPhit);
+                    const float Rorth = (n1 * cosI - n2 * cosT) / (n1 * cosI + n2 * cosT);
+                    const float Rpar = (n2 * cosI - n1 * cosT) / (n2 * cosI + n1 * cosT);
+                    rCoef = (Rorth * Rorth + Rpar * Rpar) / 2;
+                } else {
+                    rCoef = 1;
+                }
+            }
+            if (reflective && depth <= A.max_depth) {                                    // raytracer.cpp:385-388
+                want_refl = true;
+                r_refl.d = (neg(h.n) * 2.0f) * dot(h.n, ray.d) + ray.d;
+                r_refl.o = hitPt + h.n * bias;
+            }
+            if (refractive && depth <= A.max_depth && sinSqrPhit <= 1) {                 // raytracer.cpp:391-396
+                want_refr = true;
+                r_refr.d = ray.d * n + refractNormal * (n * cosI - cosT);
+                r_refr.o = hitPt - refractNormal * bias;
+            }
+            rec_b.z = h.mat;
+            rec_b.w = NODE_VALID | NODE_HIT | ((want_refl || want_refr) ? NODE_FOLD : 0u);
+        }
+    }
+
+    // append child rays to the next level: one atomic per wave
+    want_refl = want_refl && writer;
+    want_refr = want_refr && writer;
+    uint32_t s1, s2;
+    wave_append2(next_count, want_refl, want_refr, s1, s2);
+    if (want_refl) {
+        const uint64_t slot = (uint64_t)next_base + s1;
+        if (slot < A.pool_cap) {
+            A.rays[2 * (size_t)(slot - A.n0)] = make_float4(r_refl.o.x, r_refl.o.y, r_refl.o.z, 0);
+            A.rays[2 * (size_t)(slot - A.n0) + 1] = make_float4(r_refl.d.x, r_refl.d.y, r_refl.d.z, 0);
+            rec_b.x = (uint32_t)slot;
+        } else {
+            *A.overflow = 1;
+        }
+    }
+    if (want_refr) {
+        const uint64_t slot = (uint64_t)next_base + s2;
+        if (slot < A.pool_cap) {
+            A.rays[2 * (size_t)(slot - A.n0)] = make_float4(r_refr.o.x, r_refr.o.y, r_refr.o.z, 0);
+            A.rays[2 * (size_t)(slot - A.n0) + 1] = make_float4(r_refr.d.x, r_refr.d.y, r_refr.d.z, 0);
+            rec_b.y = (uint32_t)slot;
+        } else {
+            *A.overflow = 1;
+        }
+    }
+    if (active && writer) {
+        A.node_b[i] = rec_b;
+        if (rec_b.w & NODE_HIT) {
+            A.hit_n[i] = make_float4(h.n.x, h.n.y, h.n.z, h.tmpdist);
+            A.hit_p[i] = make_float4(hitPt.x, hitPt.y, hitPt.z, rCoef);
+        } else if (rec_b.w & NODE_VALID) {
+            A.node_a[i] = make_float4(A.background[0], A.background[1], A.background[2], 0);   // raytracer.cpp:302-304
+        } else {
+            A.node_a[i] = make_float4(0, 0, 0, 0);
+        }
+    }
+}
+
+__device__ __forceinline__ HitState fresh_hit() {
+    HitState h;
+    h.dist = FLT_MAX; h.n = mk(0, 0, 0); h.cur = -1; h.mat = 0;
+    h.tmpdist = 0;     // uninitialised in the reference (raytracer.cpp:285); defined as 0
+    return h;
+}
+
+// k_extend_wide: one ray per lane. Rays that never reach a mesh are finished here; the others are queued.
+template <int SRC, bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) void k_extend_wide(DScene S, LevelArgs A) {
     uint32_t begin = 0, end = A.n0;
     if (SRC == 1) level_range(A, A.level, A.level, begin, end);
     const uint32_t next_base = end;               // children of this level are appended behind it
@@ -627,198 +713,215 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend(DScene S, LevelArgs A) {
     if (COUNT) { wk.t_start = wall_clock64(); wk.c_start = clock64(); }
 
     const uint32_t n_items = end - begin;
-    const uint32_t R = SRC == 1 ? rays_per_wave(n_items) : RT_BLOCK;
-    const uint32_t n_groups = (n_items + R - 1) / R;
+    const uint32_t n_groups = (n_items + RT_BLOCK - 1) / RT_BLOCK;
     for (uint32_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
-        const uint32_t i = begin + grp * R + threadIdx.x;
-        const bool active = threadIdx.x < R && i < end;
+        const uint32_t i = begin + grp * RT_BLOCK + threadIdx.x;
+        const bool active = i < end;
         Ray ray;
         ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 0);
-        bool valid = active;
-        if (active) {
-            if (SRC == 0) {
-                const uint64_t g = A.sample0 + (i - begin);
-                uint32_t x, y; uint64_t off; bool inb;
-                valid = map_pixel(A.pm, g / A.spp, x, y, off, inb);
-                if (valid) ray = cast_ray(A.cam, A.aa, x, y, (uint32_t)(g % A.spp));
-            } else if (SRC == 1) {
-                const float4 o = A.rays[2 * (size_t)(i - A.n0)], d = A.rays[2 * (size_t)(i - A.n0) + 1];
-                ray.o = f4xyz(o); ray.d = f4xyz(d);
-            } else {
-                const float* p = A.user_rays + 6 * (size_t)i;
-                ray.o = ld3(p); ray.d = ld3(p + 3);
-            }
+        const bool valid = active && fetch_ray<SRC>(A, begin, i, ray);
+        HitState h = fresh_hit();
+        int susp = -1;
+        if (!(A.debug & 2u)) susp = closest_loop<false, COUNT>(S, ray, valid, 0, h, nullptr, wk);
+        const bool parked = susp >= 0;
+        const uint32_t qslot = wave_append(A.qcount_e + A.level, parked);
+        if (parked) {
+            A.queue_e[begin + qslot] = make_uint2(i, (uint32_t)susp);
+            A.hit_n[i] = make_float4(h.n.x, h.n.y, h.n.z, h.tmpdist);
+            A.hit_p[i] = make_float4(h.dist, __int_as_float(h.cur), __uint_as_float(h.mat), 0);
         }
-
-        uint4 rec_b = make_uint4(RT_NO_CHILD, RT_NO_CHILD, 0, 0);
-        bool want_refl = false, want_refr = false;
-        Ray r_refl, r_refr;
-        r_refl.o = r_refl.d = r_refr.o = r_refr.d = mk(0, 0, 0);
-        V3 hitNormal = mk(0, 0, 0), hitPt = mk(0, 0, 0);
-        float tmpdist = 0, rCoef = 0;     // tmpdist: uninitialised in the reference (raytracer.cpp:285); defined as 0
-
-        float dist = FLT_MAX;
-        uint32_t mat_id = 0;
-        int cur = -1;
-        if (!(A.debug & 2u)) cur = closest_hit<COUNT>(S, ray, valid, dist, hitNormal, tmpdist, mat_id, lds_stack, wk);
-        if (A.debug & 4u) cur = -1;
-        if (valid) {
-            rec_b.w = NODE_VALID;
-            if (cur >= 0) {
-                const rt_material* mp = S.materials + mat_id;
-                const float refractiveIdx = mp->refractiveIdx;
-                const bool reflective = mp->reflective != 0, refractive = mp->refractive != 0;
-                const float bias = 0.0001f;                                                  // raytracer.cpp:286
-                hitPt = ray_point(ray, dist);
-                const int depth = A.level + 1;                                               // raytracer.cpp:347
-                V3 refractNormal = hitNormal;
-                float cosI = 0, cosT = 0, sinSqrPhit = 0, n1 = 0, n2 = 0, n = 0;
-                if (refractive && depth <= A.max_depth) {                                    // raytracer.cpp:357-381
-                    cosI = dot(ray.d, hitNormal);
-                    if (cosI < 0.0f) { n1 = 1.0f; n2 = refractiveIdx; cosI = -cosI; }
-                    else { n1 = refractiveIdx; n2 = 1.0f; refractNormal = neg(refractNormal); }
-                    n = n1 / n2;
-                    sinSqrPhit = n * n * (1 - cosI * cosI);
-                    if (sinSqrPhit <= 1) {
-                        cosT = sqrtf(1 - sinSqrPhit);
-                        const float Rorth = (n1 * cosI - n2 * cosT) / (n1 * cosI + n2 * cosT);
-                        const float Rpar = (n2 * cosI - n1 * cosT) / (n2 * cosI + n1 * cosT);
-                        rCoef = (Rorth * Rorth + Rpar * Rpar) / 2;
-                    } else {
-                        rCoef = 1;
-                    }
-                }
-                if (reflective && depth <= A.max_depth) {                                    // raytracer.cpp:385-388
-                    want_refl = true;
-                    r_refl.d = (neg(hitNormal) * 2.0f) * dot(hitNormal, ray.d) + ray.d;
-                    r_refl.o = hitPt + hitNormal * bias;
-                }
-                if (refractive && depth <= A.max_depth && sinSqrPhit <= 1) {                 // raytracer.cpp:391-396
-                    want_refr = true;
-                    r_refr.d = ray.d * n + refractNormal * (n * cosI - cosT);
-                    r_refr.o = hitPt - refractNormal * bias;
-                }
-                rec_b.z = mat_id;
-                rec_b.w = NODE_VALID | NODE_HIT | ((want_refl || want_refr) ? NODE_FOLD : 0u);
-            }
-        }
-
-        // append child rays to the next level: one atomic per wave
-        uint32_t s1, s2;
-        wave_append2(next_count, want_refl, want_refr, s1, s2);
-        if (want_refl) {
-            const uint64_t slot = (uint64_t)next_base + s1;
-            if (slot < A.pool_cap) {
-                A.rays[2 * (size_t)(slot - A.n0)] = make_float4(r_refl.o.x, r_refl.o.y, r_refl.o.z, 0);
-                A.rays[2 * (size_t)(slot - A.n0) + 1] = make_float4(r_refl.d.x, r_refl.d.y, r_refl.d.z, 0);
-                rec_b.x = (uint32_t)slot;
-            } else {
-                *A.overflow = 1;
-            }
-        }
-        if (want_refr) {
-            const uint64_t slot = (uint64_t)next_base + s2;
-            if (slot < A.pool_cap) {
-                A.rays[2 * (size_t)(slot - A.n0)] = make_float4(r_refr.o.x, r_refr.o.y, r_refr.o.z, 0);
-                A.rays[2 * (size_t)(slot - A.n0) + 1] = make_float4(r_refr.d.x, r_refr.d.y, r_refr.d.z, 0);
-                rec_b.y = (uint32_t)slot;
-            } else {
-                *A.overflow = 1;
-            }
-        }
-        if (active) {
-            A.node_b[i] = rec_b;
-            if (rec_b.w & NODE_HIT) {
-                A.hit_n[i] = make_float4(hitNormal.x, hitNormal.y, hitNormal.z, tmpdist);
-                A.hit_p[i] = make_float4(hitPt.x, hitPt.y, hitPt.z, rCoef);
-            } else if (rec_b.w & NODE_VALID) {
-                A.node_a[i] = make_float4(A.background[0], A.background[1], A.background[2], 0);   // raytracer.cpp:302-304
-            } else {
-                A.node_a[i] = make_float4(0, 0, 0, 0);
-            }
-        }
+        extend_finish(S, A, i, active && !parked, valid && !parked, true, ray, h, next_base, next_count);
     }
     if (COUNT) flush_work(A.work, 0, wk);
+}
+
+// Rays per wave of a quad kernel: 16, or fewer when the items would not fill the chip's wave slots anyway (a wave
+// lasts as long as its longest ray; with everything resident at once, thinner waves end sooner).
+__device__ __forceinline__ uint32_t quads_per_wave(uint32_t n_items) {
+    const uint32_t slots = gridDim.x < 4096u ? gridDim.x : 4096u;
+    const uint32_t per = (n_items + slots - 1) / slots;
+    return per < 1u ? 1u : (per < 16u ? per : 16u);
+}
+
+// k_extend_quad: one ray per quad. FRESH: all rays of the level from the start (levels with few rays: no per-lane
+// kernel runs for them). !FRESH: the rays k_extend_wide queued, resumed at the mesh they stopped at.
+template <int SRC, bool FRESH, bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) void k_extend_quad(DScene S, LevelArgs A) {
+    __shared__ uint32_t lds_stack[RT_QSTACK * 16];
+    const uint32_t quad = threadIdx.x >> 2, j = threadIdx.x & 3u;
+    uint32_t* qs = lds_stack + quad;
+
+    uint32_t begin = 0, end = A.n0;
+    if (SRC == 1) level_range(A, A.level, A.level, begin, end);
+    const uint32_t next_base = end;
+    uint32_t* next_count = A.counters + (A.level + 1);
+    Work wk = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (COUNT) { wk.t_start = wall_clock64(); wk.c_start = clock64(); }
+
+    uint32_t n_items = end - begin;
+    if (!FRESH) { n_items = A.qcount_e[A.level]; n_items = n_items < end - begin ? n_items : end - begin; }
+    const uint32_t R = quads_per_wave(n_items);
+    const uint32_t n_groups = (n_items + R - 1) / R;
+    for (uint32_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const uint32_t idx = grp * R + quad;
+        const bool active = quad < R && idx < n_items;
+        uint32_t i = begin + idx, k0 = 0;
+        HitState h = fresh_hit();
+        if (!FRESH && active) {
+            const uint2 e = A.queue_e[begin + idx];
+            i = e.x; k0 = e.y;
+            const float4 a = A.hit_n[i], b = A.hit_p[i];
+            h.n = f4xyz(a); h.tmpdist = a.w; h.dist = b.x; h.cur = __float_as_int(b.y); h.mat = __float_as_uint(b.z);
+        }
+        Ray ray;
+        ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 0);
+        const bool valid = active && fetch_ray<SRC>(A, begin, i, ray);
+        if (COUNT) { wk.batches++; }
+        unsigned long long c0 = 0;
+        if (COUNT) c0 = wall_clock64();
+        if (!(A.debug & 2u)) closest_loop<true, COUNT>(S, ray, valid, k0, h, qs, wk);
+        if (COUNT) wk.trav_ticks += wall_clock64() - c0;
+        extend_finish(S, A, i, active, valid, j == 0, ray, h, next_base, next_count);
+    }
+    if (COUNT) flush_work(A.work, 2, wk);
     if (COUNT && A.wave_log && lane_id() == 0)
         A.wave_log[blockIdx.x] = make_uint4((uint32_t)wk.t_start, (uint32_t)wall_clock64(), (uint32_t)wk.trav_ticks, (uint32_t)(clock64() - wk.c_start));
 }
 
-// Light loop of trace() (reference src/raytracer.cpp:311-345) for the hits of levels A.level..A.level_hi.
+// Light loop of trace() (reference src/raytracer.cpp:311-345) for one hit, starting at light li0 / object k0 of its
+// shadow loop (0/0, or where the per-lane kernel suspended). Writes node_a[i]; on suspension (QUAD = false) node_a[i]
+// holds {colour so far, tmpdist} and `parked` gets (li << 16) | k. Convergent.
+template <bool QUAD, bool COUNT>
+__device__ __forceinline__ void shade_ray(const DScene& S, const LevelArgs& A, uint32_t i, uint4 b, bool hit, bool writer,
+                                          V3 hitNormal, V3 hitPt, float rCoef, float tmpdist, uint32_t li0, uint32_t k0,
+                                          bool resumed, V3 color, uint32_t* qs, Work& wk, uint32_t& n_shadow, int& parked) {
+    const rt_material m = S.materials[b.z];
+    const float bias = 0.0001f;                                                          // raytracer.cpp:286
+    bool red = false;
+    parked = -1;
+    // the loop runs for the whole wave; `live` says whether this lane is still in ITS light loop
+    for (uint32_t li = 0; li < S.n_lights; ++li) {                                       // raytracer.cpp:311-345
+        const bool live = hit && !red && parked < 0 && li >= li0;
+        const float4 lp = as_f4(ldc4(S.lights, 2 * li)), lc = as_f4(ldc4(S.lights, 2 * li + 1));
+        V3 lv = f4xyz(lp) - hitPt;
+        const float ldist = length(lv);
+        lv = normalize(lv);
+        Ray sr;
+        sr.o = hitPt + hitNormal * bias;
+        sr.d = lv;
+        n_shadow += live && writer && !(resumed && li == li0);      // a resumed ray was counted when it was shot
+        int sk;
+        const bool occ = occluded_loop<QUAD, COUNT>(S, sr, live && !(A.debug & 1u), li == li0 ? k0 : 0u, ldist, tmpdist, sk, qs, wk);
+        if (live && sk >= 0) { parked = (int)((li << 16) | (uint32_t)sk); continue; }
+        if (!live || occ) continue;
+        if (isnan3(hitNormal)) { red = true; continue; }                                 // raytracer.cpp:330-332
+        const float cosPhi = max_std(dot(hitNormal, lv), 0.0f);
+        const float fd = cosPhi / (ldist * ldist);
+        color = color + mk(((m.color[0] * lc.x) * m.kd) * fd, ((m.color[1] * lc.y) * m.kd) * fd,
+                           ((m.color[2] * lc.z) * m.kd) * fd);
+        const V3 reflectRay = (hitNormal * 2.0f) * dot(hitNormal, lv) - lv;
+        const float cosAlpha = max_std(dot(reflectRay, lv), 0.0f);
+        const float fs = (float)(spec_pow((double)cosAlpha, m.specRefExp) / (double)(ldist * ldist));
+        color = color + mk((lc.x * m.ks) * fs, (lc.y * m.ks) * fs, (lc.z * m.ks) * fs);
+    }
+    if (!hit || !writer) return;
+    if (parked >= 0) {
+        A.node_a[i] = make_float4(color.x, color.y, color.z, tmpdist);
+    } else if (red) {
+        A.node_a[i] = make_float4(1, 0, 0, 0);
+        if (b.w & NODE_FOLD) {      // children were appended speculatively: ignore them, and un-count them
+            A.node_b[i].w = NODE_VALID;
+            uint32_t lo = 0, hi = 0;
+            int lv = 0;
+            for (; lv < RT_MAX_LEVELS; ++lv) { level_range(A, lv, lv, lo, hi); if (i < hi) break; }
+            atomicAdd(A.cancelled + lv + 1, (b.x != RT_NO_CHILD ? 1u : 0u) + (b.y != RT_NO_CHILD ? 1u : 0u));
+        }
+    } else if (b.w & NODE_FOLD) {
+        A.node_a[i] = make_float4(color.x, color.y, color.z, rCoef);
+    } else {
+        const V3 c = finish_color(color, m, rCoef, mk(0, 0, 0), mk(0, 0, 0));
+        A.node_a[i] = make_float4(c.x, c.y, c.z, rCoef);
+    }
+}
+
+__device__ __forceinline__ void flush_shadow(const LevelArgs& A, uint32_t n_shadow) {
+    // statistics: one atomic per wave, spread over RT_STAT_SHARDS words
+    const uint32_t ns = wave_sum(n_shadow);
+    if (lane_id() == 0 && ns) atomicAdd(A.shadow_count + (blockIdx.x & (RT_STAT_SHARDS - 1)), (unsigned long long)ns);
+}
+
+// k_shade_wide: light loop, one hit per lane, for the hits of levels A.level..A.level_hi. Hits whose shadow rays never
+// reach a mesh are finished here; the others are queued (queue of A.level) at the point they stopped.
 template <bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) void k_shade(DScene S, LevelArgs A) {
+__global__ __launch_bounds__(RT_BLOCK) void k_shade_wide(DScene S, LevelArgs A) {
+    uint32_t begin = 0, end = A.n0;
+    if (A.level_hi > 0) level_range(A, A.level, A.level_hi, begin, end);
+    Work wk = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (COUNT) { wk.t_start = wall_clock64(); wk.c_start = clock64(); }
+    uint32_t n_shadow = 0;
+    const uint32_t n_items = end - begin;
+    const uint32_t n_groups = (n_items + RT_BLOCK - 1) / RT_BLOCK;
+    for (uint32_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+        const uint32_t i = begin + grp * RT_BLOCK + threadIdx.x;
+        uint4 b = make_uint4(0, 0, 0, 0);
+        if (i < end) b = A.node_b[i];
+        const bool hit = (b.w & NODE_HIT) != 0;
+        if (!__any(hit)) continue;                                                           // wave-uniform
+        float4 hn = make_float4(0, 0, 0, 0), hp = make_float4(0, 0, 0, 0);
+        if (hit) { hn = A.hit_n[i]; hp = A.hit_p[i]; }
+        int parked;
+        shade_ray<false, COUNT>(S, A, i, b, hit, true, f4xyz(hn), f4xyz(hp), hp.w, hn.w, 0, 0, false, mk(0, 0, 0), nullptr, wk,
+                                n_shadow, parked);
+        const uint32_t qslot = wave_append(A.qcount_s + A.level, parked >= 0);
+        if (parked >= 0) A.queue_s[begin + qslot] = make_uint2(i, (uint32_t)parked);
+    }
+    flush_shadow(A, n_shadow);
+    if (COUNT) flush_work(A.work, 1, wk);
+}
+
+// k_shade_quad: light loop, one hit per quad. FRESH: all hits of levels A.level..A.level_hi from the start.
+// !FRESH: the hits k_shade_wide queued for level A.level, resumed where they stopped.
+template <bool FRESH, bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) void k_shade_quad(DScene S, LevelArgs A) {
     __shared__ uint32_t lds_stack[RT_QSTACK * 16];
+    const uint32_t quad = threadIdx.x >> 2, j = threadIdx.x & 3u;
+    uint32_t* qs = lds_stack + quad;
 
     uint32_t begin = 0, end = A.n0;
     if (A.level_hi > 0) level_range(A, A.level, A.level_hi, begin, end);
     Work wk = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (COUNT) { wk.t_start = wall_clock64(); wk.c_start = clock64(); }
     uint32_t n_shadow = 0;
-
-    const uint32_t n_items = end - begin;
-    const uint32_t R = A.level_hi > 0 ? rays_per_wave(n_items) : RT_BLOCK;
+    uint32_t n_items = end - begin;
+    if (!FRESH) { n_items = A.qcount_s[A.level]; n_items = n_items < end - begin ? n_items : end - begin; }
+    const uint32_t R = quads_per_wave(n_items);
     const uint32_t n_groups = (n_items + R - 1) / R;
     for (uint32_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
-        const uint32_t i = begin + grp * R + threadIdx.x;
-        const bool active = threadIdx.x < R && i < end;
+        const uint32_t idx = grp * R + quad;
+        const bool active = quad < R && idx < n_items;
+        uint32_t i = begin + idx, li0 = 0, k0 = 0;
+        if (!FRESH && active) {
+            const uint2 e = A.queue_s[begin + idx];
+            i = e.x; li0 = e.y >> 16; k0 = e.y & 0xFFFFu;
+        }
         uint4 b = make_uint4(0, 0, 0, 0);
         if (active) b = A.node_b[i];
         const bool hit = (b.w & NODE_HIT) != 0;
         if (!__any(hit)) continue;                                                           // wave-uniform
         float4 hn = make_float4(0, 0, 0, 0), hp = make_float4(0, 0, 0, 0);
-        if (hit) { hn = A.hit_n[i]; hp = A.hit_p[i]; }
-        const V3 hitNormal = f4xyz(hn), hitPt = f4xyz(hp);
-        float tmpdist = hn.w;
-        const float rCoef = hp.w;
-        const rt_material m = S.materials[b.z];
-        const float bias = 0.0001f;                                                          // raytracer.cpp:286
         V3 color = mk(0, 0, 0);
-        bool red = false;
-        // the light loop runs convergent (the mesh traversal inside occluded() is a wave-level operation); `live`
-        // says whether this lane is still in ITS light loop
-        for (uint32_t li = 0; li < S.n_lights; ++li) {                                       // raytracer.cpp:311-345
-            const bool live = hit && !red;
-            const float4 lp = as_f4(ldc4(S.lights, 2 * li)), lc = as_f4(ldc4(S.lights, 2 * li + 1));
-            V3 lv = f4xyz(lp) - hitPt;
-            const float ldist = length(lv);
-            lv = normalize(lv);
-            Ray sr;
-            sr.o = hitPt + hitNormal * bias;
-            sr.d = lv;
-            n_shadow += live;
-            const bool occ = occluded<COUNT>(S, sr, live && !(A.debug & 1u), ldist, tmpdist, lds_stack, wk);
-            if (!live || occ) continue;
-            if (isnan3(hitNormal)) { red = true; continue; }                                 // raytracer.cpp:330-332
-            const float cosPhi = max_std(dot(hitNormal, lv), 0.0f);
-            const float fd = cosPhi / (ldist * ldist);
-            color = color + mk(((m.color[0] * lc.x) * m.kd) * fd, ((m.color[1] * lc.y) * m.kd) * fd,
-                               ((m.color[2] * lc.z) * m.kd) * fd);
-            const V3 reflectRay = (hitNormal * 2.0f) * dot(hitNormal, lv) - lv;
-            const float cosAlpha = max_std(dot(reflectRay, lv), 0.0f);
-            const float fs = (float)(spec_pow((double)cosAlpha, m.specRefExp) / (double)(ldist * ldist));
-            color = color + mk((lc.x * m.ks) * fs, (lc.y * m.ks) * fs, (lc.z * m.ks) * fs);
+        float tmpdist = 0;
+        if (hit) {
+            hn = A.hit_n[i]; hp = A.hit_p[i];
+            tmpdist = hn.w;
+            if (!FRESH) { const float4 c = A.node_a[i]; color = f4xyz(c); tmpdist = c.w; }
         }
-        if (!hit) continue;
-        if (red) {
-            A.node_a[i] = make_float4(1, 0, 0, 0);
-            if (b.w & NODE_FOLD) {      // children were appended speculatively: ignore them, and un-count them
-                A.node_b[i].w = NODE_VALID;
-                uint32_t lo = 0, hi = 0;
-                int lv = A.level;
-                for (; lv <= A.level_hi; ++lv) { level_range(A, lv, lv, lo, hi); if (i < hi) break; }
-                atomicAdd(A.cancelled + lv + 1, (b.x != RT_NO_CHILD ? 1u : 0u) + (b.y != RT_NO_CHILD ? 1u : 0u));
-            }
-        } else if (b.w & NODE_FOLD) {
-            A.node_a[i] = make_float4(color.x, color.y, color.z, rCoef);
-        } else {
-            const V3 c = finish_color(color, m, rCoef, mk(0, 0, 0), mk(0, 0, 0));
-            A.node_a[i] = make_float4(c.x, c.y, c.z, rCoef);
-        }
+        int parked;
+        shade_ray<true, COUNT>(S, A, i, b, hit, j == 0, f4xyz(hn), f4xyz(hp), hp.w, tmpdist, li0, k0, !FRESH, color, qs, wk,
+                               n_shadow, parked);
     }
-
-    // statistics: one atomic per wave, spread over RT_STAT_SHARDS words
-    const uint32_t ns = wave_sum(n_shadow);
-    if (lane_id() == 0 && ns) atomicAdd(A.shadow_count + (blockIdx.x & (RT_STAT_SHARDS - 1)), (unsigned long long)ns);
-    if (COUNT) flush_work(A.work, 1, wk);
+    flush_shadow(A, n_shadow);
+    if (COUNT) flush_work(A.work, 3, wk);
 }
 
 // Colour of pool node i once its children (one level deeper) are final.
@@ -909,33 +1012,51 @@ __global__ __launch_bounds__(RT_BLOCK) void k_cast_rays(DCamera cam, const float
     o[0] = r.o.x; o[1] = r.o.y; o[2] = r.o.z; o[3] = r.d.x; o[4] = r.d.y; o[5] = r.d.z;
 }
 
+// One ray per quad (16 rays per workgroup), the same loops the render kernels use.
 __global__ __launch_bounds__(RT_BLOCK) void k_intersect(DScene S, int object, const float* __restrict__ rays, uint32_t n,
                                                         int32_t* __restrict__ hit_obj, float* __restrict__ dist_out,
                                                         float* __restrict__ normal_out) {
     __shared__ uint32_t lds_stack[RT_QSTACK * 16];
-    const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    const uint32_t quad = threadIdx.x >> 2, j = threadIdx.x & 3u;
+    const uint32_t i = blockIdx.x * 16 + quad;
     const bool alive = i < n;
     Ray ray;
     ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 0);
     if (alive) { ray.o = ld3(rays + 6 * (size_t)i); ray.d = ld3(rays + 6 * (size_t)i + 3); }
     Work wk = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    HitState h = fresh_hit();
     float d = 0;
     V3 nrm = mk(0, 0, 0);
     int hit = -1;
     if (object >= 0) {
+        // that object only: Primitive::intersect(ray, dist, normal) with dist = 0 on entry
         const u32x4 ob = ldc4(S.objects, 2 * object), pb = ldc4(S.objects, 2 * object + 1);
         const float4 prm = as_f4(pb);
-        bool h = false;
-        if (ob.x == RT_OBJ_SPHERE) { if (alive) h = sphere_isect(prm, __uint_as_float(ob.w), ray, d, nrm); }
-        else if (ob.x == RT_OBJ_PLANE) { if (alive) h = plane_isect(prm, ray, d, nrm); }
-        else h = model_closest<false>(S, load_model(S.models, ob.y), ray, alive, d, nrm, lds_stack, wk);
-        if (h) hit = object;
+        bool got = false;
+        if (ob.x == RT_OBJ_SPHERE) { if (alive) got = sphere_isect(prm, __uint_as_float(ob.w), ray, d, nrm); }
+        else if (ob.x == RT_OBJ_PLANE) { if (alive) got = plane_isect(prm, ray, d, nrm); }
+        else {
+            const ModelRef m = load_model(S.models, ob.y);
+            bool need = alive;
+            if (alive) d = FLT_MAX;
+            if (m.bb.w >= 0) need = alive && sphere_gate(m.bb, ray);
+            if (need) {
+                QuadHit q;
+                quad_traverse<false, false>(S, m.root, true, ray, FLT_MAX, q, lds_stack + quad, wk);
+                if (q.face != 0xFFFFFFFFu) {
+                    const float4* np = reinterpret_cast<const float4*>(S.normals + q.face);
+                    d = q.t;
+                    nrm = (f4xyz(np[0]) * (1 - q.u - q.v) + f4xyz(np[1]) * q.u) + f4xyz(np[2]) * q.v;
+                    got = true;
+                }
+            }
+        }
+        if (got) hit = object;
     } else {
-        float tmp = 0;
-        uint32_t mat;
-        hit = closest_hit<false>(S, ray, alive, d, nrm, tmp, mat, lds_stack, wk);
+        closest_loop<true, false>(S, ray, alive, 0, h, lds_stack + quad, wk);
+        hit = h.cur; d = h.dist; nrm = h.n;
     }
-    if (!alive) return;
+    if (!alive || j != 0) return;
     hit_obj[i] = hit;
     dist_out[i] = d;
     normal_out[3 * (size_t)i] = nrm.x; normal_out[3 * (size_t)i + 1] = nrm.y; normal_out[3 * (size_t)i + 2] = nrm.z;
@@ -944,7 +1065,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_intersect(DScene S, int object, co
 __global__ __launch_bounds__(RT_BLOCK) void k_occluded(DScene S, const float* __restrict__ rays, const float* __restrict__ max_dist,
                                                        uint32_t n, uint8_t* __restrict__ occ) {
     __shared__ uint32_t lds_stack[RT_QSTACK * 16];
-    const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    const uint32_t quad = threadIdx.x >> 2, j = threadIdx.x & 3u;
+    const uint32_t i = blockIdx.x * 16 + quad;
     const bool alive = i < n;
     Ray ray;
     ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 0);
@@ -952,8 +1074,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_occluded(DScene S, const float* __
     if (alive) { ray.o = ld3(rays + 6 * (size_t)i); ray.d = ld3(rays + 6 * (size_t)i + 3); md = max_dist[i]; }
     Work wk = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     float tmp = 0;
-    const bool in = occluded<false>(S, ray, alive, md, tmp, lds_stack, wk);
-    if (alive) occ[i] = in ? 1 : 0;
+    int sk;
+    const bool in = occluded_loop<true, false>(S, ray, alive, 0, md, tmp, sk, lds_stack + quad, wk);
+    if (alive && j == 0) occ[i] = in ? 1 : 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -961,23 +1084,42 @@ __global__ __launch_bounds__(RT_BLOCK) void k_occluded(DScene S, const float* __
 // ---------------------------------------------------------------------------------------------------------
 extern "C++" {
 
-void launch_extend(int src, bool count, const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st) {
-    dim3 g(grid), b(RT_BLOCK);
-    if (src == 0) {
-        if (count) hipLaunchKernelGGL((k_extend<0, true>), g, b, 0, st, S, A);
-        else hipLaunchKernelGGL((k_extend<0, false>), g, b, 0, st, S, A);
-    } else if (src == 1) {
-        if (count) hipLaunchKernelGGL((k_extend<1, true>), g, b, 0, st, S, A);
-        else hipLaunchKernelGGL((k_extend<1, false>), g, b, 0, st, S, A);
+static uint32_t debug_lds() {   // timing experiments only: extra LDS per workgroup caps the waves per CU
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("RT_DEBUG_LDS"); v = e ? atoi(e) : 0; }
+    return (uint32_t)v;
+}
+template <int SRC>
+static void launch_extend_src(int form, bool count, const DScene& S, const LevelArgs& A, dim3 g, hipStream_t st) {
+    dim3 b(RT_BLOCK);
+    if (form == RT_FORM_WIDE) {
+        if (count) hipLaunchKernelGGL((k_extend_wide<SRC, true>), g, b, 0, st, S, A);
+        else hipLaunchKernelGGL((k_extend_wide<SRC, false>), g, b, 0, st, S, A);
+    } else if (form == RT_FORM_QUAD_FRESH) {
+        if (count) hipLaunchKernelGGL((k_extend_quad<SRC, true, true>), g, b, debug_lds(), st, S, A);
+        else hipLaunchKernelGGL((k_extend_quad<SRC, true, false>), g, b, debug_lds(), st, S, A);
     } else {
-        if (count) hipLaunchKernelGGL((k_extend<2, true>), g, b, 0, st, S, A);
-        else hipLaunchKernelGGL((k_extend<2, false>), g, b, 0, st, S, A);
+        if (count) hipLaunchKernelGGL((k_extend_quad<SRC, false, true>), g, b, debug_lds(), st, S, A);
+        else hipLaunchKernelGGL((k_extend_quad<SRC, false, false>), g, b, debug_lds(), st, S, A);
     }
 }
-void launch_shade(bool count, const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st) {
+void launch_extend(int src, int form, bool count, const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st) {
+    if (src == 0) launch_extend_src<0>(form, count, S, A, dim3(grid), st);
+    else if (src == 1) launch_extend_src<1>(form, count, S, A, dim3(grid), st);
+    else launch_extend_src<2>(form, count, S, A, dim3(grid), st);
+}
+void launch_shade(int form, bool count, const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st) {
     dim3 g(grid), b(RT_BLOCK);
-    if (count) hipLaunchKernelGGL((k_shade<true>), g, b, 0, st, S, A);
-    else hipLaunchKernelGGL((k_shade<false>), g, b, 0, st, S, A);
+    if (form == RT_FORM_WIDE) {
+        if (count) hipLaunchKernelGGL((k_shade_wide<true>), g, b, 0, st, S, A);
+        else hipLaunchKernelGGL((k_shade_wide<false>), g, b, 0, st, S, A);
+    } else if (form == RT_FORM_QUAD_FRESH) {
+        if (count) hipLaunchKernelGGL((k_shade_quad<true, true>), g, b, 0, st, S, A);
+        else hipLaunchKernelGGL((k_shade_quad<true, false>), g, b, 0, st, S, A);
+    } else {
+        if (count) hipLaunchKernelGGL((k_shade_quad<false, true>), g, b, 0, st, S, A);
+        else hipLaunchKernelGGL((k_shade_quad<false, false>), g, b, 0, st, S, A);
+    }
 }
 void launch_fold(const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st) {
     hipLaunchKernelGGL(k_fold, dim3(grid), dim3(256), 0, st, S, A);
@@ -1000,10 +1142,10 @@ void launch_cast_rays(const DCamera& cam, const float* aa, uint32_t spp, const u
 }
 void launch_intersect(const DScene& S, int object, const float* rays, uint32_t n, int32_t* hit, float* dist, float* nrm,
                       hipStream_t st) {
-    hipLaunchKernelGGL(k_intersect, dim3((n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, st, S, object, rays, n, hit, dist, nrm);
+    hipLaunchKernelGGL(k_intersect, dim3((n + 15) / 16), dim3(RT_BLOCK), 0, st, S, object, rays, n, hit, dist, nrm);
 }
 void launch_occluded(const DScene& S, const float* rays, const float* max_dist, uint32_t n, uint8_t* occ, hipStream_t st) {
-    hipLaunchKernelGGL(k_occluded, dim3((n + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, st, S, rays, max_dist, n, occ);
+    hipLaunchKernelGGL(k_occluded, dim3((n + 15) / 16), dim3(RT_BLOCK), 0, st, S, rays, max_dist, n, occ);
 }
 
 }  // extern "C++"

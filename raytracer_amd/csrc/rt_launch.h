@@ -7,7 +7,7 @@
 
 #define RT_BLOCK 64          // one wave per workgroup: waves retire independently, no barrier is ever needed
 #define RT_MAX_LEVELS 16     // recursion levels 0..max_depth, max_depth <= 15
-#define RT_WORK_SHARDS 64      // COUNT builds: [shard][kernel 0/1][12] words
+#define RT_WORK_SHARDS 64      // COUNT builds: [shard][kernel 0..3][12] words
 #define RT_STAT_SHARDS 256    // statistics atomics are spread over this many words: one word saturates at ~90 atomics/us
 
 // Scene in HBM (SoA). All pointers are device pointers owned by rt_scene.
@@ -21,7 +21,7 @@ struct DScene {
     const rt_material* materials;
     const float4* lights;        // 2 per light: pos, color
     const Bvh4Node* nodes;
-    const TriIsect* tris;        // leaf order
+    const LeafBlock* leaves;
     const TriNormals* normals;   // original face order
 };
 
@@ -62,12 +62,17 @@ struct LevelArgs {
     uint32_t* cancelled;         // [RT_MAX_LEVELS+1] per level: speculative children whose parent took the red exit
     uint32_t* overflow;          // set to 1 if a child did not fit
     unsigned long long* shadow_count;   // [RT_STAT_SHARDS], indexed by workgroup
-    unsigned long long* work;    // [RT_WORK_SHARDS][2][12] traversal work counters (COUNT builds only)
+    unsigned long long* work;    // [RT_WORK_SHARDS][4][12] traversal work counters (COUNT builds only)
     float4* rays;                // 2 per pool entry >= n0: origin, direction
     float4* node_a;              // per pool entry: r g b rCoef
     uint4* node_b;               // per pool entry: refl child, refr child, material, flags
     float4* hit_n;               // per pool entry with a hit: hitNormal xyz, tmpdist as the closest-hit loop left it
     float4* hit_p;               // per pool entry with a hit: hitPt xyz, rCoef
+    uint2* queue_e;              // per pool entry: rays k_extend_wide suspended {pool entry, object index}; a level's
+                                 // queue starts at the level's pool offset
+    uint2* queue_s;              // same for k_shade_wide {pool entry, light << 16 | object}
+    uint32_t* qcount_e;          // [RT_MAX_LEVELS+1] queue lengths per level
+    uint32_t* qcount_s;
     const float* aa;             // anti-aliasing pattern (device)
     const float* user_rays;      // SRC 2
     float background[3];
@@ -82,8 +87,10 @@ struct UntileArgs {
     uint32_t part_stride;   // tile slots between parts; 0 = packed
 };
 
-void launch_extend(int src, bool count, const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st);
-void launch_shade(bool count, const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st);
+// Kernel forms: one ray per lane (suspends at meshes), one ray per quad from the start, one per quad resuming the queue.
+enum { RT_FORM_WIDE = 0, RT_FORM_QUAD_FRESH = 1, RT_FORM_QUAD_RESUME = 2 };
+void launch_extend(int src, int form, bool count, const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st);
+void launch_shade(int form, bool count, const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st);
 void launch_fold(const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st);
 void launch_resolve(const DScene& S, const LevelArgs& A, uint8_t* out, hipStream_t st);
 void launch_resolve_rgb(const DScene& S, const LevelArgs& A, float* rgb, hipStream_t st);
