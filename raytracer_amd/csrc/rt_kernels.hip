@@ -22,7 +22,6 @@
 // exactly where the reference's overload resolution computes in double (sphere roots, pow, camera tan product).
 #include <hip/hip_runtime.h>
 #include <float.h>
-#include <stdlib.h>
 #include <stdint.h>
 
 #include "rt_device.h"
@@ -762,7 +761,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_quad(DScene S, LevelArgs A)
     if (!FRESH) { n_items = A.qcount_e[A.level]; n_items = n_items < end - begin ? n_items : end - begin; }
     const uint32_t R = quads_per_wave(n_items);
     const uint32_t n_groups = (n_items + R - 1) / R;
-    for (uint32_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    // Workgroup -> group mapping: workgroups whose ids are congruent mod 256 tend to share a CU (ids go round-robin
+    // over the 8 XCDs, then over an XCD's CUs), so they get CONSECUTIVE groups: neighbouring rays, the same part of
+    // the tree, in the same 32-KB L1.
+    const uint32_t per_cu = (n_groups + 255u) >> 8;
+    for (uint32_t vb = blockIdx.x; vb < per_cu * 256u; vb += gridDim.x) {
+        const uint32_t grp = (vb & 255u) * per_cu + (vb >> 8);
+        if (grp >= n_groups) continue;
         const uint32_t idx = grp * R + quad;
         const bool active = quad < R && idx < n_items;
         uint32_t i = begin + idx, k0 = 0;
@@ -896,7 +901,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade_quad(DScene S, LevelArgs A) 
     if (!FRESH) { n_items = A.qcount_s[A.level]; n_items = n_items < end - begin ? n_items : end - begin; }
     const uint32_t R = quads_per_wave(n_items);
     const uint32_t n_groups = (n_items + R - 1) / R;
-    for (uint32_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    // Workgroup -> group mapping: workgroups whose ids are congruent mod 256 tend to share a CU (ids go round-robin
+    // over the 8 XCDs, then over an XCD's CUs), so they get CONSECUTIVE groups: neighbouring rays, the same part of
+    // the tree, in the same 32-KB L1.
+    const uint32_t per_cu = (n_groups + 255u) >> 8;
+    for (uint32_t vb = blockIdx.x; vb < per_cu * 256u; vb += gridDim.x) {
+        const uint32_t grp = (vb & 255u) * per_cu + (vb >> 8);
+        if (grp >= n_groups) continue;
         const uint32_t idx = grp * R + quad;
         const bool active = quad < R && idx < n_items;
         uint32_t i = begin + idx, li0 = 0, k0 = 0;
@@ -916,6 +927,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade_quad(DScene S, LevelArgs A) 
             tmpdist = hn.w;
             if (!FRESH) { const float4 c = A.node_a[i]; color = f4xyz(c); tmpdist = c.w; }
         }
+        if (COUNT) wk.batches++;
         int parked;
         shade_ray<true, COUNT>(S, A, i, b, hit, j == 0, f4xyz(hn), f4xyz(hp), hp.w, tmpdist, li0, k0, !FRESH, color, qs, wk,
                                n_shadow, parked);
@@ -1084,11 +1096,6 @@ __global__ __launch_bounds__(RT_BLOCK) void k_occluded(DScene S, const float* __
 // ---------------------------------------------------------------------------------------------------------
 extern "C++" {
 
-static uint32_t debug_lds() {   // timing experiments only: extra LDS per workgroup caps the waves per CU
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("RT_DEBUG_LDS"); v = e ? atoi(e) : 0; }
-    return (uint32_t)v;
-}
 template <int SRC>
 static void launch_extend_src(int form, bool count, const DScene& S, const LevelArgs& A, dim3 g, hipStream_t st) {
     dim3 b(RT_BLOCK);
@@ -1096,11 +1103,11 @@ static void launch_extend_src(int form, bool count, const DScene& S, const Level
         if (count) hipLaunchKernelGGL((k_extend_wide<SRC, true>), g, b, 0, st, S, A);
         else hipLaunchKernelGGL((k_extend_wide<SRC, false>), g, b, 0, st, S, A);
     } else if (form == RT_FORM_QUAD_FRESH) {
-        if (count) hipLaunchKernelGGL((k_extend_quad<SRC, true, true>), g, b, debug_lds(), st, S, A);
-        else hipLaunchKernelGGL((k_extend_quad<SRC, true, false>), g, b, debug_lds(), st, S, A);
+        if (count) hipLaunchKernelGGL((k_extend_quad<SRC, true, true>), g, b, 0, st, S, A);
+        else hipLaunchKernelGGL((k_extend_quad<SRC, true, false>), g, b, 0, st, S, A);
     } else {
-        if (count) hipLaunchKernelGGL((k_extend_quad<SRC, false, true>), g, b, debug_lds(), st, S, A);
-        else hipLaunchKernelGGL((k_extend_quad<SRC, false, false>), g, b, debug_lds(), st, S, A);
+        if (count) hipLaunchKernelGGL((k_extend_quad<SRC, false, true>), g, b, 0, st, S, A);
+        else hipLaunchKernelGGL((k_extend_quad<SRC, false, false>), g, b, 0, st, S, A);
     }
 }
 void launch_extend(int src, int form, bool count, const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st) {
