@@ -74,7 +74,8 @@ struct Builder {
         uint32_t need = 0;
         while ((uint64_t(RT_MAX_LEAF_TRIS) << need) < n) ++need;
         uint32_t mid = 0;
-        if (!balanced && depth + need + 1 < RT_BVH2_MAX_DEPTH) mid = sah_split(b, e, bx);
+        if (!balanced && n <= 4 * RT_MAX_LEAF_TRIS) mid = full_leaf_split(b, e);
+        else if (!balanced && depth + need + 1 < RT_BVH2_MAX_DEPTH) mid = sah_split(b, e, bx);
         if (mid <= b || mid >= e) mid = median_split(b, e, bx);
 
         const uint32_t idx = n_nodes2.fetch_add(1);
@@ -146,6 +147,36 @@ struct Builder {
         depth = dmax + 1;
         stack = smax + uint32_t(k - 1);
         return idx;
+    }
+
+    // Small ranges (<= 4 leaves' worth): a leaf costs the quad one step whether it holds 1 or 4 triangles, so only
+    // splits that leave a multiple of RT_MAX_LEAF_TRIS on the left are considered (full leaves, fewer nodes); among
+    // them the surface-area cost in leaf steps decides.
+    uint32_t full_leaf_split(uint32_t b, uint32_t e) {
+        const uint32_t n = e - b;
+        float best_cost = INFINITY;
+        int best_axis = 0;
+        uint32_t best_c = RT_MAX_LEAF_TRIS;
+        std::vector<uint32_t> tmp(order.begin() + b, order.begin() + e);
+        for (int axis = 0; axis < 3; ++axis) {
+            std::sort(tmp.begin(), tmp.end(), [&](uint32_t x, uint32_t y) {
+                const float cx = centroid[3 * size_t(x) + axis], cy = centroid[3 * size_t(y) + axis];
+                return cx < cy || (cx == cy && x < y);
+            });
+            for (uint32_t c = RT_MAX_LEAF_TRIS; c < n; c += RT_MAX_LEAF_TRIS) {
+                Box l, r; l.reset(); r.reset();
+                for (uint32_t i = 0; i < c; ++i) l.grow(tri_box[tmp[i]]);
+                for (uint32_t i = c; i < n; ++i) r.grow(tri_box[tmp[i]]);
+                const float cost = l.half_area() * float((c + RT_MAX_LEAF_TRIS - 1) / RT_MAX_LEAF_TRIS) +
+                                   r.half_area() * float((n - c + RT_MAX_LEAF_TRIS - 1) / RT_MAX_LEAF_TRIS);
+                if (cost < best_cost) { best_cost = cost; best_axis = axis; best_c = c; }
+            }
+        }
+        std::sort(order.begin() + b, order.begin() + e, [&](uint32_t x, uint32_t y) {
+            const float cx = centroid[3 * size_t(x) + best_axis], cy = centroid[3 * size_t(y) + best_axis];
+            return cx < cy || (cx == cy && x < y);
+        });
+        return b + best_c;
     }
 
     uint32_t median_split(uint32_t b, uint32_t e, const Box& bx) {

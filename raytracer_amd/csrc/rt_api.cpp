@@ -62,8 +62,8 @@ enum { RT_K_EXTEND_WIDE = 0, RT_K_SHADE_WIDE = 1, RT_K_EXTEND_QUAD = 2, RT_K_SHA
 struct rt_scene {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t shade_stream = nullptr;   // k_shade runs here, next to k_extend of the deeper levels
-    hipEvent_t ev_sync[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t shade_stream[2] = {nullptr, nullptr};   // the shade kernels run here, next to the extend kernels
+    hipEvent_t ev_sync[2 * RT_MAX_LEVELS + 4] = {};      // per level: per-lane extend done, quad extend done; joins
     DScene d{};                        // device pointers
     std::vector<void*> owned;          // everything to hipFree
     uint32_t n_models = 0, n_faces = 0, n_nodes = 0, bvh_depth = 0;
@@ -102,7 +102,7 @@ static int free_scene(rt_scene* s) {
     if (s->ev_end) hipEventDestroy(s->ev_end);
     for (hipEvent_t e : s->ev_pool) hipEventDestroy(e);
     for (hipEvent_t e : s->ev_sync) if (e) hipEventDestroy(e);
-    if (s->shade_stream) hipStreamDestroy(s->shade_stream);
+    for (hipStream_t st : s->shade_stream) if (st) hipStreamDestroy(st);
     if (s->stream) hipStreamDestroy(s->stream);
     delete s;
     return RT_OK;
@@ -154,7 +154,8 @@ extern "C" int rt_scene_create(const rt_flat_scene* sc, int device, rt_scene** o
     s->device = device;
     auto fail = [&](int code) { bvh_free(&bvh); free_scene(s); return code; };
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&s->shade_stream, hipStreamNonBlocking) != hipSuccess) { rt_set_error("hipStreamCreate failed"); return fail(RT_ERR_DEVICE); }
+        hipStreamCreateWithFlags(&s->shade_stream[0], hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&s->shade_stream[1], hipStreamNonBlocking) != hipSuccess) { rt_set_error("hipStreamCreate failed"); return fail(RT_ERR_DEVICE); }
     for (hipEvent_t& e : s->ev_sync)
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { rt_set_error("hipEventCreate failed"); return fail(RT_ERR_DEVICE); }
 
@@ -353,16 +354,19 @@ static bool expect_large(const rt_scene* s, int lo, int hi) {
 // Enqueue the passes covering pixels [px0, px0+npx) of the frame's pixel order, pass_px pixels at a time.
 // Records which PassCounters slot each pass used in `slots` (px0, npx, slot).
 //
-// One recursion level = closest hits (E) then, independently, the light loop of those hits (S). Each runs either as
-//   Ew + Eq   per-lane kernel that finishes the rays that never reach a mesh and queues the others, then the quad
-//             kernel that resumes the queue (large levels; scenes without meshes run Ew / Sw alone), or
-//   Ef        the quad kernel on all rays of the level (small levels: one launch less on the dependent chain).
-// Schedule of one pass with L bounce levels (F = k_fold):
-//   stream A (the caller's):  E0  E1  E2 ... EL                      | F(L-1) ... F1  resolve
-//   stream B (shade_stream):      S0  S1            S(2..L)          |
-// S never feeds E, so the level-to-level chain on A is one closest-hit traversal per level; the shadow traversals of
-// level k run next to the closest-hit traversals of the levels below it. A waits for B before folding. A timed frame
-// (stats requested) issues the same launches on ONE stream, so that each kernel's duration is its own.
+// One recursion level = closest hits (extend) then, independently, the light loop of those hits (shade).
+//   large level (or a scene without meshes):
+//     Ew   per-lane extend: finishes the rays that never reach a mesh, parks the others in the level's queue
+//     Eq   quad extend: resumes the parked rays                                      (scenes with meshes only)
+//     Sw   per-lane shade of the hits Ew finished; parks the hits whose shadow rays reach a mesh
+//     Sq   quad shade: resumes what Sw parked
+//     Sp   quad shade of the hits Eq produced
+//   small level: Ef = quad extend of all its rays; small levels are shaded together at the end by Sf (quad).
+// Streams (an untimed frame): the extend kernels form the dependent chain and run on the caller's stream A; the
+// shade kernels feed nothing but the fold, so level k's run on shade stream k%2 as soon as their input exists
+// (Sw, Sq after Ew; Sp after Eq), next to Eq and the extend kernels of the deeper levels. A waits for both shade
+// streams before folding. A timed frame (stats requested) issues the same launches on ONE stream, so that each
+// kernel's duration is its own.
 struct PassRec { uint64_t px0; uint32_t npx; uint32_t slot; };
 
 static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass_px, std::vector<PassRec>& recs) {
@@ -385,11 +389,12 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
         A.shadow_count = pc->shadow;
         A.work = &pc->work[0][0][0];
         const int levels = s->has_bounce ? A.max_depth : 0;
-        const bool overlap = !J.timed && levels >= 1;
-        hipStream_t sa = J.st, sb = overlap ? s->shade_stream : J.st;
+        const bool overlap = !J.timed;
+        hipStream_t sa = J.st;
         const uint32_t grid0 = (A.n0 + RT_BLOCK - 1) / RT_BLOCK;
         const uint32_t grid0q = std::min<uint32_t>((A.n0 + 15) / 16, 4u * RT_LEVEL_GRID);
         int rc;
+        bool used_shade[2] = {false, false};
         // diagnostics: RT_WAVE_LOG=<level>:<file> dumps per-workgroup timing of that level's quad extend kernel (COUNT builds)
         uint4* wave_log = nullptr;
         int log_level = -1;
@@ -402,37 +407,49 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
                 if (wave_log) hipMemsetAsync(wave_log, 0, sizeof(uint4) * 4u * RT_LEVEL_GRID, sa);
             }
         }
-        auto extend = [&](int lv) -> int {
+        // shade launch `form` over levels lo..hi on the level's shade stream, after event `after` of stream A
+        auto shade = [&](int form, int lo, int hi, int after) -> int {
+            hipStream_t sb = overlap ? s->shade_stream[lo & 1] : sa;
+            if (overlap) {
+                HIP_TRY(hipStreamWaitEvent(sb, s->ev_sync[after], 0));
+                used_shade[lo & 1] = true;
+            }
+            LevelArgs B = A;
+            B.level = lo; B.level_hi = hi;
+            const uint32_t g = form == RT_FORM_WIDE ? (hi == 0 ? grid0 : RT_LEVEL_GRID)
+                               : (hi == 0 ? grid0q : (form == RT_FORM_QUAD_FRESH ? RT_LEVEL_GRID : 4u * RT_LEVEL_GRID));
+            return timed_launch(J, sb, form == RT_FORM_WIDE ? RT_K_SHADE_WIDE : RT_K_SHADE_QUAD,
+                                [&] { launch_shade(form, s->count_work, s->d, B, g, sb); });
+        };
+        int small_lo = -1;      // first level of the run of small levels not shaded yet
+        for (int lv = 0; lv <= levels; ++lv) {
             LevelArgs B = A;
             B.level = lv; B.level_hi = lv;
             const int src = lv == 0 ? 0 : 1;
             const bool large = !meshes || expect_large(s, lv, lv);
             if (large) {
+                if (small_lo >= 0) {     // shade the small levels before this one
+                    if (overlap) HIP_TRY(hipEventRecord(s->ev_sync[2 * lv], sa));
+                    if ((rc = shade(RT_FORM_QUAD_FRESH, small_lo, lv - 1, 2 * lv)) != RT_OK) return rc;
+                    small_lo = -1;
+                }
                 if ((rc = timed_launch(J, sa, RT_K_EXTEND_WIDE, [&] { launch_extend(src, RT_FORM_WIDE, s->count_work, s->d, B, lv == 0 ? grid0 : RT_LEVEL_GRID, sa); })) != RT_OK) return rc;
-                if (!meshes) return RT_OK;
+                if (overlap) HIP_TRY(hipEventRecord(s->ev_sync[2 * lv], sa));
+                if (meshes) {
+                    B.wave_log = (lv == log_level) ? wave_log : nullptr;
+                    if ((rc = timed_launch(J, sa, RT_K_EXTEND_QUAD, [&] { launch_extend(src, RT_FORM_QUAD_RESUME, s->count_work, s->d, B, lv == 0 ? grid0q : 4u * RT_LEVEL_GRID, sa); })) != RT_OK) return rc;
+                    if (overlap) HIP_TRY(hipEventRecord(s->ev_sync[2 * lv + 1], sa));
+                }
+                if ((rc = shade(RT_FORM_WIDE, lv, lv, 2 * lv)) != RT_OK) return rc;
+                if (meshes) {
+                    if ((rc = shade(RT_FORM_QUAD_RESUME, lv, lv, 2 * lv)) != RT_OK) return rc;
+                    if ((rc = shade(RT_FORM_QUAD_PARKED, lv, lv, 2 * lv + 1)) != RT_OK) return rc;
+                }
+            } else {
+                B.wave_log = (lv == log_level) ? wave_log : nullptr;
+                if ((rc = timed_launch(J, sa, RT_K_EXTEND_QUAD, [&] { launch_extend(src, RT_FORM_QUAD_FRESH, s->count_work, s->d, B, RT_LEVEL_GRID, sa); })) != RT_OK) return rc;
+                if (small_lo < 0) small_lo = lv;
             }
-            B.wave_log = (lv == log_level) ? wave_log : nullptr;
-            const uint32_t g = lv == 0 ? grid0q : (large ? 4u * RT_LEVEL_GRID : RT_LEVEL_GRID);
-            return timed_launch(J, sa, RT_K_EXTEND_QUAD, [&] { launch_extend(src, large ? RT_FORM_QUAD_RESUME : RT_FORM_QUAD_FRESH, s->count_work, s->d, B, g, sa); });
-        };
-        auto shade = [&](int lo, int hi, int ev) -> int {
-            if (overlap) {
-                HIP_TRY(hipEventRecord(s->ev_sync[ev], sa));
-                HIP_TRY(hipStreamWaitEvent(sb, s->ev_sync[ev], 0));
-            }
-            LevelArgs B = A;
-            B.level = lo; B.level_hi = hi;
-            const bool large = !meshes || expect_large(s, lo, hi);
-            if (large) {
-                if ((rc = timed_launch(J, sb, RT_K_SHADE_WIDE, [&] { launch_shade(RT_FORM_WIDE, s->count_work, s->d, B, hi == 0 ? grid0 : RT_LEVEL_GRID, sb); })) != RT_OK) return rc;
-                if (!meshes) return RT_OK;
-            }
-            const uint32_t g = hi == 0 ? grid0q : (large ? 4u * RT_LEVEL_GRID : RT_LEVEL_GRID);
-            return timed_launch(J, sb, RT_K_SHADE_QUAD, [&] { launch_shade(large ? RT_FORM_QUAD_RESUME : RT_FORM_QUAD_FRESH, s->count_work, s->d, B, g, sb); });
-        };
-        for (int lv = 0; lv <= levels; ++lv) {
-            if ((rc = extend(lv)) != RT_OK) return rc;
-            if (lv <= 1 && (rc = shade(lv, lv, lv)) != RT_OK) return rc;
         }
         if (wave_log) {
             std::vector<uint4> h(4u * RT_LEVEL_GRID);
@@ -441,11 +458,16 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
             if (FILE* f = std::fopen(log_path, "wb")) { std::fwrite(h.data(), sizeof(uint4), h.size(), f); std::fclose(f); }
             hipFree(wave_log);
         }
-        if (levels >= 2 && (rc = shade(2, levels, 2)) != RT_OK) return rc;
-        if (overlap) {
-            HIP_TRY(hipEventRecord(s->ev_sync[3], sb));
-            HIP_TRY(hipStreamWaitEvent(sa, s->ev_sync[3], 0));
+        if (small_lo >= 0) {
+            const int ev = 2 * RT_MAX_LEVELS;
+            if (overlap) HIP_TRY(hipEventRecord(s->ev_sync[ev], sa));
+            if ((rc = shade(RT_FORM_QUAD_FRESH, small_lo, levels, ev)) != RT_OK) return rc;
         }
+        for (int k = 0; k < 2; ++k)
+            if (used_shade[k]) {
+                HIP_TRY(hipEventRecord(s->ev_sync[2 * RT_MAX_LEVELS + 1 + k], s->shade_stream[k]));
+                HIP_TRY(hipStreamWaitEvent(sa, s->ev_sync[2 * RT_MAX_LEVELS + 1 + k], 0));
+            }
         for (int lv = levels - 1; lv >= 1; --lv) {
             A.level = lv; A.level_hi = lv;
             launch_fold(s->d, A, 1024, sa);
@@ -756,7 +778,13 @@ static int trace_chunk(rt_scene* s, const rt_params* prm, const float* d_rays, u
     }
     A.level = 0; A.level_hi = levels;
     launch_shade(RT_FORM_WIDE, s->count_work, s->d, A, std::max<uint32_t>((n + RT_BLOCK - 1) / RT_BLOCK, levels ? RT_LEVEL_GRID : 1u), st);
-    if (meshes) launch_shade(RT_FORM_QUAD_RESUME, s->count_work, s->d, A, 4u * RT_LEVEL_GRID, st);
+    if (meshes) {
+        launch_shade(RT_FORM_QUAD_RESUME, s->count_work, s->d, A, 4u * RT_LEVEL_GRID, st);
+        for (int lv = 0; lv <= levels; ++lv) {      // the hits of the rays each level parked
+            A.level = lv; A.level_hi = lv;
+            launch_shade(RT_FORM_QUAD_PARKED, s->count_work, s->d, A, lv == 0 ? gq : 4u * RT_LEVEL_GRID, st);
+        }
+    }
     for (int lv = levels - 1; lv >= 1; --lv) { A.level = lv; A.level_hi = lv; launch_fold(s->d, A, 1024, st); }
     A.level = 0; A.level_hi = 0;
     launch_resolve_rgb(s->d, A, d_rgb, st);

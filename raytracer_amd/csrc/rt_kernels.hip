@@ -541,6 +541,8 @@ __device__ __forceinline__ bool map_pixel(const PixelMap& pm, uint64_t q, uint32
 //   SRC 2: level 0, rays supplied by the caller (rt_trace)
 // ---------------------------------------------------------------------------------------------------------
 #define NODE_HIT 4u      // has a hit record: k_shade computes its colour
+#define NODE_PARKED 8u   // the ray went through the extend queue: its hit is shaded from that queue (k_shade_quad<2>),
+                         // not by k_shade_wide, which may run before the queue has been worked off
 
 // Pool range [begin, end) of levels lo..hi (level 0 = [0, n0), level k >= 1 behind level k-1). 64-bit sums: after an
 // overflow the counters hold the ATTEMPTED appends (flagged by the producing level).
@@ -607,7 +609,7 @@ __device__ __forceinline__ bool fetch_ray(const LevelArgs& A, uint32_t begin, ui
 // the per-lane kernels, lane 0 of the quad in the quad kernels). Called with the whole wave converged.
 __device__ __forceinline__ void extend_finish(const DScene& S, const LevelArgs& A, uint32_t i, bool active, bool valid,
                                               bool writer, const Ray& ray, const HitState& h, uint32_t next_base,
-                                              uint32_t* next_count) {
+                                              uint32_t* next_count, uint32_t extra_flags) {
     uint4 rec_b = make_uint4(RT_NO_CHILD, RT_NO_CHILD, 0, 0);
     bool want_refl = false, want_refr = false;
     Ray r_refl, r_refr;
@@ -682,6 +684,7 @@ __device__ __forceinline__ void extend_finish(const DScene& S, const LevelArgs& 
         }
     }
     if (active && writer) {
+        rec_b.w |= extra_flags;
         A.node_b[i] = rec_b;
         if (rec_b.w & NODE_HIT) {
             A.hit_n[i] = make_float4(h.n.x, h.n.y, h.n.z, h.tmpdist);
@@ -725,11 +728,12 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_wide(DScene S, LevelArgs A)
         const bool parked = susp >= 0;
         const uint32_t qslot = wave_append(A.qcount_e + A.level, parked);
         if (parked) {
+            A.node_b[i] = make_uint4(RT_NO_CHILD, RT_NO_CHILD, 0, NODE_PARKED);
             A.queue_e[begin + qslot] = make_uint2(i, (uint32_t)susp);
             A.hit_n[i] = make_float4(h.n.x, h.n.y, h.n.z, h.tmpdist);
             A.hit_p[i] = make_float4(h.dist, __int_as_float(h.cur), __uint_as_float(h.mat), 0);
         }
-        extend_finish(S, A, i, active && !parked, valid && !parked, true, ray, h, next_base, next_count);
+        extend_finish(S, A, i, active && !parked, valid && !parked, true, ray, h, next_base, next_count, 0u);
     }
     if (COUNT) flush_work(A.work, 0, wk);
 }
@@ -786,7 +790,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_quad(DScene S, LevelArgs A)
         if (COUNT) c0 = wall_clock64();
         if (!(A.debug & 2u)) closest_loop<true, COUNT>(S, ray, valid, k0, h, qs, wk);
         if (COUNT) wk.trav_ticks += wall_clock64() - c0;
-        extend_finish(S, A, i, active, valid, j == 0, ray, h, next_base, next_count);
+        extend_finish(S, A, i, active, valid, j == 0, ray, h, next_base, next_count, FRESH ? 0u : NODE_PARKED);
     }
     if (COUNT) flush_work(A.work, 2, wk);
     if (COUNT && A.wave_log && lane_id() == 0)
@@ -800,7 +804,9 @@ template <bool QUAD, bool COUNT>
 __device__ __forceinline__ void shade_ray(const DScene& S, const LevelArgs& A, uint32_t i, uint4 b, bool hit, bool writer,
                                           V3 hitNormal, V3 hitPt, float rCoef, float tmpdist, uint32_t li0, uint32_t k0,
                                           bool resumed, V3 color, uint32_t* qs, Work& wk, uint32_t& n_shadow, int& parked) {
-    const rt_material m = S.materials[b.z];
+    // the material is fetched where it is used (after the shadow test) rather than held in registers across the
+    // traversal: the quad kernels are register-bound
+    const rt_material* mp = S.materials + b.z;
     const float bias = 0.0001f;                                                          // raytracer.cpp:286
     bool red = false;
     parked = -1;
@@ -820,14 +826,16 @@ __device__ __forceinline__ void shade_ray(const DScene& S, const LevelArgs& A, u
         if (live && sk >= 0) { parked = (int)((li << 16) | (uint32_t)sk); continue; }
         if (!live || occ) continue;
         if (isnan3(hitNormal)) { red = true; continue; }                                 // raytracer.cpp:330-332
+        const float4 mc = *reinterpret_cast<const float4*>(mp);            // color[3], ka
+        const float4 mk4 = *(reinterpret_cast<const float4*>(mp) + 1);      // kd, ks, kr, kt
+        const float specRefExp = mp->specRefExp;
         const float cosPhi = max_std(dot(hitNormal, lv), 0.0f);
         const float fd = cosPhi / (ldist * ldist);
-        color = color + mk(((m.color[0] * lc.x) * m.kd) * fd, ((m.color[1] * lc.y) * m.kd) * fd,
-                           ((m.color[2] * lc.z) * m.kd) * fd);
+        color = color + mk(((mc.x * lc.x) * mk4.x) * fd, ((mc.y * lc.y) * mk4.x) * fd, ((mc.z * lc.z) * mk4.x) * fd);
         const V3 reflectRay = (hitNormal * 2.0f) * dot(hitNormal, lv) - lv;
         const float cosAlpha = max_std(dot(reflectRay, lv), 0.0f);
-        const float fs = (float)(spec_pow((double)cosAlpha, m.specRefExp) / (double)(ldist * ldist));
-        color = color + mk((lc.x * m.ks) * fs, (lc.y * m.ks) * fs, (lc.z * m.ks) * fs);
+        const float fs = (float)(spec_pow((double)cosAlpha, specRefExp) / (double)(ldist * ldist));
+        color = color + mk((lc.x * mk4.y) * fs, (lc.y * mk4.y) * fs, (lc.z * mk4.y) * fs);
     }
     if (!hit || !writer) return;
     if (parked >= 0) {
@@ -844,6 +852,7 @@ __device__ __forceinline__ void shade_ray(const DScene& S, const LevelArgs& A, u
     } else if (b.w & NODE_FOLD) {
         A.node_a[i] = make_float4(color.x, color.y, color.z, rCoef);
     } else {
+        const rt_material m = *mp;
         const V3 c = finish_color(color, m, rCoef, mk(0, 0, 0), mk(0, 0, 0));
         A.node_a[i] = make_float4(c.x, c.y, c.z, rCoef);
     }
@@ -870,7 +879,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade_wide(DScene S, LevelArgs A) 
         const uint32_t i = begin + grp * RT_BLOCK + threadIdx.x;
         uint4 b = make_uint4(0, 0, 0, 0);
         if (i < end) b = A.node_b[i];
-        const bool hit = (b.w & NODE_HIT) != 0;
+        const bool hit = (b.w & (NODE_HIT | NODE_PARKED)) == NODE_HIT;
         if (!__any(hit)) continue;                                                           // wave-uniform
         float4 hn = make_float4(0, 0, 0, 0), hp = make_float4(0, 0, 0, 0);
         if (hit) { hn = A.hit_n[i]; hp = A.hit_p[i]; }
@@ -884,10 +893,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade_wide(DScene S, LevelArgs A) 
     if (COUNT) flush_work(A.work, 1, wk);
 }
 
-// k_shade_quad: light loop, one hit per quad. FRESH: all hits of levels A.level..A.level_hi from the start.
-// !FRESH: the hits k_shade_wide queued for level A.level, resumed where they stopped.
-template <bool FRESH, bool COUNT>
+// k_shade_quad: light loop, one hit per quad.
+//   MODE 0  all hits of levels A.level..A.level_hi, from the start
+//   MODE 1  the hits k_shade_wide queued (queue_s of A.level), resumed where they stopped
+//   MODE 2  the hits of the rays that went through the extend queue (queue_e of A.level), from the start
+template <int MODE, bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK) void k_shade_quad(DScene S, LevelArgs A) {
+    constexpr bool FRESH = MODE != 1;
     __shared__ uint32_t lds_stack[RT_QSTACK * 16];
     const uint32_t quad = threadIdx.x >> 2, j = threadIdx.x & 3u;
     uint32_t* qs = lds_stack + quad;
@@ -898,7 +910,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade_quad(DScene S, LevelArgs A) 
     if (COUNT) { wk.t_start = wall_clock64(); wk.c_start = clock64(); }
     uint32_t n_shadow = 0;
     uint32_t n_items = end - begin;
-    if (!FRESH) { n_items = A.qcount_s[A.level]; n_items = n_items < end - begin ? n_items : end - begin; }
+    if (MODE != 0) {
+        const uint32_t q = MODE == 1 ? A.qcount_s[A.level] : A.qcount_e[A.level];
+        n_items = q < end - begin ? q : end - begin;
+    }
     const uint32_t R = quads_per_wave(n_items);
     const uint32_t n_groups = (n_items + R - 1) / R;
     // Workgroup -> group mapping: workgroups whose ids are congruent mod 256 tend to share a CU (ids go round-robin
@@ -911,10 +926,11 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade_quad(DScene S, LevelArgs A) 
         const uint32_t idx = grp * R + quad;
         const bool active = quad < R && idx < n_items;
         uint32_t i = begin + idx, li0 = 0, k0 = 0;
-        if (!FRESH && active) {
+        if (MODE == 1 && active) {
             const uint2 e = A.queue_s[begin + idx];
             i = e.x; li0 = e.y >> 16; k0 = e.y & 0xFFFFu;
         }
+        if (MODE == 2 && active) i = A.queue_e[begin + idx].x;
         uint4 b = make_uint4(0, 0, 0, 0);
         if (active) b = A.node_b[i];
         const bool hit = (b.w & NODE_HIT) != 0;
@@ -1121,11 +1137,14 @@ void launch_shade(int form, bool count, const DScene& S, const LevelArgs& A, uin
         if (count) hipLaunchKernelGGL((k_shade_wide<true>), g, b, 0, st, S, A);
         else hipLaunchKernelGGL((k_shade_wide<false>), g, b, 0, st, S, A);
     } else if (form == RT_FORM_QUAD_FRESH) {
-        if (count) hipLaunchKernelGGL((k_shade_quad<true, true>), g, b, 0, st, S, A);
-        else hipLaunchKernelGGL((k_shade_quad<true, false>), g, b, 0, st, S, A);
+        if (count) hipLaunchKernelGGL((k_shade_quad<0, true>), g, b, 0, st, S, A);
+        else hipLaunchKernelGGL((k_shade_quad<0, false>), g, b, 0, st, S, A);
+    } else if (form == RT_FORM_QUAD_RESUME) {
+        if (count) hipLaunchKernelGGL((k_shade_quad<1, true>), g, b, 0, st, S, A);
+        else hipLaunchKernelGGL((k_shade_quad<1, false>), g, b, 0, st, S, A);
     } else {
-        if (count) hipLaunchKernelGGL((k_shade_quad<false, true>), g, b, 0, st, S, A);
-        else hipLaunchKernelGGL((k_shade_quad<false, false>), g, b, 0, st, S, A);
+        if (count) hipLaunchKernelGGL((k_shade_quad<2, true>), g, b, 0, st, S, A);
+        else hipLaunchKernelGGL((k_shade_quad<2, false>), g, b, 0, st, S, A);
     }
 }
 void launch_fold(const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st) {

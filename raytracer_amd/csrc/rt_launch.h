@@ -88,7 +88,8 @@ struct UntileArgs {
 };
 
 // Kernel forms: one ray per lane (suspends at meshes), one ray per quad from the start, one per quad resuming the queue.
-enum { RT_FORM_WIDE = 0, RT_FORM_QUAD_FRESH = 1, RT_FORM_QUAD_RESUME = 2 };
+// RT_FORM_QUAD_PARKED (shade only): one hit per quad from the start, for the rays of the level's extend queue.
+enum { RT_FORM_WIDE = 0, RT_FORM_QUAD_FRESH = 1, RT_FORM_QUAD_RESUME = 2, RT_FORM_QUAD_PARKED = 3 };
 void launch_extend(int src, int form, bool count, const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st);
 void launch_shade(int form, bool count, const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st);
 void launch_fold(const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st);
