@@ -62,8 +62,9 @@ enum { RT_K_EXTEND_WIDE = 0, RT_K_SHADE_WIDE = 1, RT_K_EXTEND_QUAD = 2, RT_K_SHA
 struct rt_scene {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t shade_stream[2] = {nullptr, nullptr};   // the shade kernels run here, next to the extend kernels
-    hipEvent_t ev_sync[2 * RT_MAX_LEVELS + 4] = {};      // per level: per-lane extend done, quad extend done; joins
+    hipStream_t shade_stream[3] = {nullptr, nullptr, nullptr};   // the shade kernels run here, next to the extend kernels:
+                                                                 // large levels on [level & 1], runs of small levels on [2]
+    hipEvent_t ev_sync[2 * RT_MAX_LEVELS + 5] = {};      // per level: per-lane extend done, quad extend done; joins
     DScene d{};                        // device pointers
     std::vector<void*> owned;          // everything to hipFree
     uint32_t n_models = 0, n_faces = 0, n_nodes = 0, bvh_depth = 0;
@@ -153,9 +154,13 @@ extern "C" int rt_scene_create(const rt_flat_scene* sc, int device, rt_scene** o
     rt_scene* s = new rt_scene();
     s->device = device;
     auto fail = [&](int code) { bvh_free(&bvh); free_scene(s); return code; };
+    // the shade streams get the LOWEST priority: their kernels fill idle slots, the extend chain must not wait for them
+    int prio_least = 0, prio_greatest = 0;
+    hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&s->shade_stream[0], hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&s->shade_stream[1], hipStreamNonBlocking) != hipSuccess) { rt_set_error("hipStreamCreate failed"); return fail(RT_ERR_DEVICE); }
+        hipStreamCreateWithPriority(&s->shade_stream[0], hipStreamNonBlocking, prio_least) != hipSuccess ||
+        hipStreamCreateWithPriority(&s->shade_stream[1], hipStreamNonBlocking, prio_least) != hipSuccess ||
+        hipStreamCreateWithPriority(&s->shade_stream[2], hipStreamNonBlocking, prio_least) != hipSuccess) { rt_set_error("hipStreamCreate failed"); return fail(RT_ERR_DEVICE); }
     for (hipEvent_t& e : s->ev_sync)
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { rt_set_error("hipEventCreate failed"); return fail(RT_ERR_DEVICE); }
 
@@ -394,7 +399,7 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
         const uint32_t grid0 = (A.n0 + RT_BLOCK - 1) / RT_BLOCK;
         const uint32_t grid0q = std::min<uint32_t>((A.n0 + 15) / 16, 4u * RT_LEVEL_GRID);
         int rc;
-        bool used_shade[2] = {false, false};
+        bool used_shade[3] = {false, false, false};
         // diagnostics: RT_WAVE_LOG=<level>:<file> dumps per-workgroup timing of that level's quad extend kernel (COUNT builds)
         uint4* wave_log = nullptr;
         int log_level = -1;
@@ -409,10 +414,11 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
         }
         // shade launch `form` over levels lo..hi on the level's shade stream, after event `after` of stream A
         auto shade = [&](int form, int lo, int hi, int after) -> int {
-            hipStream_t sb = overlap ? s->shade_stream[lo & 1] : sa;
+            const int which = form == RT_FORM_QUAD_FRESH ? 2 : (lo & 1);
+            hipStream_t sb = overlap ? s->shade_stream[which] : sa;
             if (overlap) {
                 HIP_TRY(hipStreamWaitEvent(sb, s->ev_sync[after], 0));
-                used_shade[lo & 1] = true;
+                used_shade[which] = true;
             }
             LevelArgs B = A;
             B.level = lo; B.level_hi = hi;
@@ -449,6 +455,11 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
                 B.wave_log = (lv == log_level) ? wave_log : nullptr;
                 if ((rc = timed_launch(J, sa, RT_K_EXTEND_QUAD, [&] { launch_extend(src, RT_FORM_QUAD_FRESH, s->count_work, s->d, B, RT_LEVEL_GRID, sa); })) != RT_OK) return rc;
                 if (small_lo < 0) small_lo = lv;
+                if (lv - small_lo + 1 >= 3 && lv < levels) {     // shade a run of three small levels while the deeper ones are traced
+                    if (overlap) HIP_TRY(hipEventRecord(s->ev_sync[2 * lv + 1], sa));
+                    if ((rc = shade(RT_FORM_QUAD_FRESH, small_lo, lv, 2 * lv + 1)) != RT_OK) return rc;
+                    small_lo = -1;
+                }
             }
         }
         if (wave_log) {
@@ -463,7 +474,7 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
             if (overlap) HIP_TRY(hipEventRecord(s->ev_sync[ev], sa));
             if ((rc = shade(RT_FORM_QUAD_FRESH, small_lo, levels, ev)) != RT_OK) return rc;
         }
-        for (int k = 0; k < 2; ++k)
+        for (int k = 0; k < 3; ++k)
             if (used_shade[k]) {
                 HIP_TRY(hipEventRecord(s->ev_sync[2 * RT_MAX_LEVELS + 1 + k], s->shade_stream[k]));
                 HIP_TRY(hipStreamWaitEvent(sa, s->ev_sync[2 * RT_MAX_LEVELS + 1 + k], 0));
