@@ -83,7 +83,11 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal only: every rank uses GPU 0 (needs --backend gloo)")
+    ap.add_argument("--watchdog", type=int, default=0, help="dump all Python stacks and exit after this many seconds")
     args = ap.parse_args()
+    if args.watchdog:
+        import faulthandler
+        faulthandler.dump_traceback_later(args.watchdog, exit=True)
 
     import numpy as np
     import torch
@@ -144,7 +148,7 @@ def main():
             if args.backend == "nccl":
                 dist.gather(mine, gathered, dst=0)
             else:       # gloo rehearsal: gloo gathers host tensors only
-                torch.cuda.current_stream().synchronize()
+                torch.cuda.synchronize()        # the render runs on the scene's own stream when `stream` is the null stream
                 host = mine.cpu()
                 hg = [torch.zeros_like(host) for _ in range(world)] if rank == 0 else None
                 dist.gather(host, hg, dst=0)

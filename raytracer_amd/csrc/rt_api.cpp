@@ -154,13 +154,12 @@ extern "C" int rt_scene_create(const rt_flat_scene* sc, int device, rt_scene** o
     rt_scene* s = new rt_scene();
     s->device = device;
     auto fail = [&](int code) { bvh_free(&bvh); free_scene(s); return code; };
-    // the shade streams get the LOWEST priority: their kernels fill idle slots, the extend chain must not wait for them
-    int prio_least = 0, prio_greatest = 0;
-    hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    // (no stream priorities: low-priority shade streams gained ~1.5 % but hung hipDeviceSynchronize when two processes
+    // shared one GPU)
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithPriority(&s->shade_stream[0], hipStreamNonBlocking, prio_least) != hipSuccess ||
-        hipStreamCreateWithPriority(&s->shade_stream[1], hipStreamNonBlocking, prio_least) != hipSuccess ||
-        hipStreamCreateWithPriority(&s->shade_stream[2], hipStreamNonBlocking, prio_least) != hipSuccess) { rt_set_error("hipStreamCreate failed"); return fail(RT_ERR_DEVICE); }
+        hipStreamCreateWithFlags(&s->shade_stream[0], hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&s->shade_stream[1], hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&s->shade_stream[2], hipStreamNonBlocking) != hipSuccess) { rt_set_error("hipStreamCreate failed"); return fail(RT_ERR_DEVICE); }
     for (hipEvent_t& e : s->ev_sync)
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { rt_set_error("hipEventCreate failed"); return fail(RT_ERR_DEVICE); }
 
