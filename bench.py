@@ -229,17 +229,35 @@ def main():
                                        "sphere_tests": wk.spheres_tested, "plane_tests": wk.planes_tested,
                                        "wave_node_steps": wk.wave_node_steps, "wave_tri_steps": wk.wave_tri_steps,
                                        "batches": wk.batches}}
+            # HBM bytes per launch from the PMC passes of tools/exp_traffic.sh (FETCH_SIZE x2 + WRITE_SIZE, separate runs;
+            # committed under profiles/r*/traffic_<workload>.json). bench.py cannot collect counters itself.
+            import glob
+            traffic = {}
+            tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"traffic_{args.workload}.json")))
+            if tf:
+                traffic = {k: v["hbm_bytes_per_launch"] for k, v in json.load(open(tf[-1]))["kernels"].items()}
+            for name in per_kernel:
+                per_kernel[name]["hbm_bytes_per_launch_pmc"] = traffic.get(name)
             dom = max(per_kernel, key=lambda k: per_kernel[k]["ms_per_frame_serial"])
             d = per_kernel[dom]
             out["roofline"] = {
                 "bound": "hbm", "kernel": dom, "achieved": d["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": d["GB/s"] / HBM_PEAK_GBS, "traffic": None,
+                "frac": d["GB/s"] / HBM_PEAK_GBS, "traffic": traffic.get(dom),
                 "avg_launch_ms": d["avg_launch_ms"], "launches_per_frame": d["launches_per_frame"],
                 "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
                 "valu": {"achieved": d["TFLOP/s"], "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": d["TFLOP/s"] / VALU_PEAK_TFLOPS},
                 "serial_frame_ms": frame_ms / reps, "kernels": per_kernel,
             }
+            # the boundary as the reference has it (rt_render: host framebuffer, synchronous): PCIe-inclusive, never `value`
+            host_frame = np.zeros((H, W, 3), np.uint8)
+            dev.render(cam, params, out=host_frame, want_stats=False)
+            t = time.perf_counter()
+            for _ in range(5):
+                dev.render(cam, params, out=host_frame, want_stats=False)
+            host_ms = (time.perf_counter() - t) / 5 * 1e3
+            out["host_framebuffer"] = {"ms_per_frame": host_ms, "Mrays/s": rays_per_frame / host_ms / 1e3,
+                                       "note": "rt_render into a host buffer (frame copied over PCIe, call synchronous)"}
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(fs, cam, params, dev, np)
         print(json.dumps(out), flush=True)

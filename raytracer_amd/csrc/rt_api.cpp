@@ -635,12 +635,14 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_params* prm
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_frame), need));
         s->frame_bytes = need;
     }
-    rt_stats local;
-    rc = render_frame(s, cam, prm, rect_map(cam, x0, y0, w, h), s->d_frame, s->stream, stats ? stats : &local, true);
+    rc = render_frame(s, cam, prm, rect_map(cam, x0, y0, w, h), s->d_frame, s->stream, stats, true);
     if (rc != RT_OK) return rc;
     finish_stats(stats, uint64_t(w) * h, 1 + prm->n_aa);
     const size_t pitch = size_t(cam->imWidth) * 3, off = (size_t(y0) * cam->imWidth + x0) * 3;
-    HIP_TRY(hipMemcpy2DAsync(bgr + off, pitch, s->d_frame + off, pitch, size_t(w) * 3, h, hipMemcpyDeviceToHost, s->stream));
+    if (w == cam->imWidth)     // whole rows: one contiguous copy (pitched copies into pageable memory are several times slower)
+        HIP_TRY(hipMemcpyAsync(bgr + off, s->d_frame + off, pitch * h, hipMemcpyDeviceToHost, s->stream));
+    else
+        HIP_TRY(hipMemcpy2DAsync(bgr + off, pitch, s->d_frame + off, pitch, size_t(w) * 3, h, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     return RT_OK;
 }

@@ -129,3 +129,56 @@ def test_frame_parity(oracle_mod, case):
         mask = np.ones((H, W), bool)
         mask[rect[1]:rect[1] + rect[3], rect[0]:rect[0] + rect[2]] = False
         assert not got[mask].any()
+
+
+def test_schedule_forms_agree(oracle_mod):
+    """The same frame through the different launch schedules: first call of a scene (level sizes unknown: per-lane
+    kernels + resumed queues at every level), second call (small levels run as one quad kernel), the asynchronous
+    multi-stream path into a device buffer, and the oracle."""
+    import torch
+    fs = wl.scene_bunny(10, third="glass2")
+    cam, p = reference_camera(320, 240), Params(max_depth=6)
+    dev = DeviceScene(fs)
+    a, st_a = dev.render(cam, p)
+    b, st_b = dev.render(cam, p)
+    assert np.array_equal(a, b)
+    assert st_a.trace_calls == st_b.trace_calls and st_a.shadow_rays == st_b.shadow_rays
+    assert list(st_a.level_rays) == list(st_b.level_rays)
+    frame = torch.zeros((240, 320, 3), dtype=torch.uint8, device="cuda")
+    for _ in range(3):     # async: no stats, shade kernels on their own streams
+        dev.render_device(cam, p, frame.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(frame.cpu().numpy(), a)
+    want, st_o = oracle_mod.Oracle(fs).render(cam, p)
+    within1, equal, worst = frame_stats(a, want)
+    assert within1 >= 0.999
+    assert st_a.trace_calls == st_o.trace_calls and st_a.shadow_rays == st_o.shadow_rays
+
+
+def test_nan_normal_red_exit(oracle_mod):
+    """trace()'s `return red` exit (reference src/raytracer.cpp:330-332): a reflective mesh whose vertex normals are NaN
+    (what calcNormal gives for a degenerate face). The HIP path appends the reflection ray before the light loop has
+    decided; colours AND ray counts must still equal the oracle's."""
+    from raytracer_amd.scene import FlatScene, Mesh, material
+    fs = FlatScene()
+    nan = float("nan")
+    tri = [[[-3, -2, -6]], [[3, -2, -6.5]], [[0, 3, -5.5]], [[nan, 0, 1]], [[0, nan, 1]], [[0, 0, nan]]]
+    fs.add_mesh(Mesh(*[np.array(a, np.float32) for a in tri], np.array([0, 0, -6, 5.0], np.float32)),
+                material((0.8, 0.8, 0.8), reflective=True, kr=0.5))
+    fs.add_sphere((0.5, 0.2, -3.0), 0.4, material((0.2, 0.9, 0.2)))          # shadows part of the triangle
+    fs.add_plane((0, 1, 0), 4.0, material((0.5, 0.5, 0.9), reflective=True, kr=0.3))
+    fs.add_light((-2, 5, 0), (1, 1, 1), 30.0)
+    fs.add_light((3, 4, -1), (1, 0.9, 0.8), 20.0)
+    cam, p = reference_camera(96, 72), Params(max_depth=4)
+    rays = camera_rays(oracle_mod, cam, p)
+    dev = DeviceScene(fs)
+    got, st1 = dev.trace(p, rays)
+    want, st2 = oracle_mod.Oracle(fs).trace(p, rays)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.array_equal(np.nan_to_num(got, nan=-1.0), np.nan_to_num(want, nan=-1.0))
+    assert (got == np.array([1, 0, 0], np.float32)).all(axis=1).any()            # the red exit was taken somewhere
+    assert st1.trace_calls == st2.trace_calls and st1.shadow_rays == st2.shadow_rays
+    f1, s1 = dev.render(cam, p)
+    f2, s2 = oracle_mod.Oracle(fs).render(cam, p)
+    assert np.array_equal(f1, f2)
+    assert s1.trace_calls == s2.trace_calls and s1.shadow_rays == s2.shadow_rays
