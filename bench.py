@@ -126,7 +126,7 @@ def main():
     if rank == 0:
         dev.set_count_work(True)
         dev.render_device(cam, params, frame.data_ptr(), stream=stream, stats=st)
-        work_k = [dev.get_work(k) for k in range(4)]
+        work_k = [dev.get_work(k) for k in range(5)]
         work_hits = st.shadow_rays // max(len(fs.lights), 1)      # shaded hits (each shoots one ray per light)
         dev.set_count_work(False)
         ref_frame = frame.clone()
@@ -200,14 +200,15 @@ def main():
             # runs them back to back on ONE stream with HIP events around every launch (the untimed path overlaps the
             # shade kernels with deeper extend launches, which would blur per-kernel durations).
             reps = 10
-            names = ("k_extend_wide", "k_shade_wide", "k_extend_quad", "k_shade_quad")
-            ms = [0.0] * 4
-            n = [0] * 4
+            names = ("k_extend_wide", "k_shade_wide", "k_extend_quad", "k_shade_quad<0|1>", "k_shade_quad<2>")
+            NK = len(names)
+            ms = [0.0] * NK
+            n = [0] * NK
             frame_ms = 0.0
             for _ in range(reps):
                 s2 = rt_stats()
                 dev.render_device(cam, params, frame.data_ptr(), stream=stream, stats=s2)
-                for k in range(4):
+                for k in range(NK):
                     ms[k] += s2.kernel_ms_by[k]; n[k] += s2.kernel_launches_by[k]
                 frame_ms += s2.kernel_ms
             per_kernel = {}
@@ -217,7 +218,7 @@ def main():
                 wk = work_k[ki]
                 # rays whose record the kernel reads or writes (48 B each in the survey's formula): a wide kernel sees
                 # every ray of its kind, a quad kernel the rays it traverses (16 per batch at most)
-                rays_k = (st.trace_calls if ki in (0, 2) else st.shadow_rays) if ki < 2 else min(16 * wk.batches, st.trace_calls if ki == 2 else st.shadow_rays)
+                rays_k = (st.trace_calls if ki == 0 else st.shadow_rays) if ki < 2 else min(16 * wk.batches, st.trace_calls if ki == 2 else st.shadow_rays)
                 b, f = algorithmic_work(wk, rays_k, work_hits if ki == 1 else 0, len(fs.lights))
                 lp = n[ki] / reps
                 avg = ms[ki] / n[ki]
@@ -236,17 +237,43 @@ def main():
             tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"traffic_{args.workload}.json")))
             if tf:
                 traffic = {k: v["hbm_bytes_per_launch"] for k, v in json.load(open(tf[-1]))["kernels"].items()}
-            for name in per_kernel:
-                per_kernel[name]["hbm_bytes_per_launch_pmc"] = traffic.get(name)
-            dom = max(per_kernel, key=lambda k: per_kernel[k]["ms_per_frame_serial"])
-            d = per_kernel[dom]
+            for name in per_kernel:     # all launches of the kernel, whatever its template arguments
+                tot = [(v, json.load(open(tf[-1]))["kernels"][k]["launches"]) for k, v in traffic.items() if k.split("<")[0] == name] if tf else []
+                per_kernel[name]["hbm_bytes_per_launch_pmc"] = (sum(v * l for v, l in tot) / sum(l for _, l in tot)) if tot else None
+            # Roofline of the dominant LAUNCH: a frame at max_depth 0 runs exactly the level-0 launches (the heaviest of
+            # the frame), so its counters and its HIP-event durations belong to single launches, which rocprofv3 lists
+            # under the same templated names.
+            from raytracer_amd.scene import Params
+            p0 = Params(background=tuple(params.c.background), max_depth=0, aa=params.aa)
+            dev.set_count_work(True)
+            s0 = rt_stats()
+            dev.render_device(cam, p0, frame.data_ptr(), stream=stream, stats=s0)
+            work0 = [dev.get_work(k) for k in range(NK)]
+            dev.set_count_work(False)
+            ms0, n0 = [0.0] * NK, [0] * NK
+            for _ in range(reps):
+                s2 = rt_stats()
+                dev.render_device(cam, p0, frame.data_ptr(), stream=stream, stats=s2)
+                for k in range(NK):
+                    ms0[k] += s2.kernel_ms_by[k]; n0[k] += s2.kernel_launches_by[k]
+            dev.render_device(cam, params, frame.data_ptr(), stream=stream)      # leave the full frame in the buffer
+            torch.cuda.synchronize()
+            rocprof_names = ("k_extend_wide<0, false>", "k_shade_wide<false>", "k_extend_quad<0, false, false>",
+                             "k_shade_quad<1, false>", "k_shade_quad<2, false>")
+            dk = max(range(NK), key=lambda k: ms0[k] / max(n0[k], 1))
+            avg = ms0[dk] / n0[dk]
+            lp = n0[dk] / reps
+            rays_k = (s0.trace_calls if dk == 0 else s0.shadow_rays) if dk < 2 else min(16 * work0[dk].batches, s0.trace_calls if dk == 2 else s0.shadow_rays)
+            b, f = algorithmic_work(work0[dk], rays_k, s0.shadow_rays // max(len(fs.lights), 1) if dk == 1 else 0, len(fs.lights))
+            gbs, tfl = b / lp / (avg * 1e-3) / 1e9, f / lp / (avg * 1e-3) / 1e12
             out["roofline"] = {
-                "bound": "hbm", "kernel": dom, "achieved": d["GB/s"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": d["GB/s"] / HBM_PEAK_GBS, "traffic": traffic.get(dom),
-                "avg_launch_ms": d["avg_launch_ms"], "launches_per_frame": d["launches_per_frame"],
-                "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
-                "valu": {"achieved": d["TFLOP/s"], "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": d["TFLOP/s"] / VALU_PEAK_TFLOPS},
+                "bound": "hbm", "kernel": rocprof_names[dk], "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": gbs / HBM_PEAK_GBS, "traffic": traffic.get(rocprof_names[dk]),
+                "avg_launch_ms": avg, "launches_per_frame": lp, "algorithmic_bytes_per_launch": b / lp,
+                "units_per_launch": {"rays": rays_k, "bvh_nodes": work0[dk].nodes_visited, "tri_tests": work0[dk].tris_tested,
+                                     "sphere_tests": work0[dk].spheres_tested, "plane_tests": work0[dk].planes_tested},
+                "valu": {"achieved": tfl, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / VALU_PEAK_TFLOPS},
+                "level0_launch_ms": {rocprof_names[k]: ms0[k] / n0[k] for k in range(NK) if n0[k]},
                 "serial_frame_ms": frame_ms / reps, "kernels": per_kernel,
             }
             # the boundary as the reference has it (rt_render: host framebuffer, synchronous): PCIe-inclusive, never `value`

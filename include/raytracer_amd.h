@@ -130,9 +130,9 @@ typedef struct rt_stats {
     uint32_t passes;          /* image passes the frame was split into                 */
     uint32_t retries;         /* passes re-run with a smaller size after queue overflow */
     float    kernel_ms;       /* HIP-event time of all kernels of this call (timed calls run on one stream) */
-    float    kernel_ms_by[4];        /* of which, summed over their launches: k_extend_wide, k_shade_wide,  */
-    uint32_t kernel_launches_by[4];  /* k_extend_quad, k_shade_quad (closest-hit / light-loop kernels, one ray per */
-    uint32_t reserved;               /* lane / per quad of lanes)                                                   */
+    float    kernel_ms_by[5];        /* of which, summed over their launches: k_extend_wide, k_shade_wide,         */
+    uint32_t kernel_launches_by[5];  /* k_extend_quad, k_shade_quad<0|1>, k_shade_quad<2> (closest-hit / light-loop */
+    uint32_t reserved;               /* kernels, one ray per lane / per quad of lanes)                              */
 } rt_stats;
 
 typedef struct rt_scene rt_scene;   /* opaque; owns the HBM copy of the scene on one device */
@@ -214,8 +214,8 @@ int rt_scene_bvh_info(const rt_scene* scene, rt_bvh_info* out);
 
 /* Traversal work of the last call that passed a non-NULL stats AND had counting enabled with
  * rt_set_count_work(1): node visits / triangle tests / sphere / plane tests summed over all rays, per kernel:
- * rt_get_work(kernel = 0: k_extend_wide, 1: k_shade_wide, 2: k_extend_quad, 3: k_shade_quad (the order of
- * rt_stats.kernel_ms_by), -1: all). */
+ * rt_get_work(kernel = 0: k_extend_wide, 1: k_shade_wide, 2: k_extend_quad, 3: k_shade_quad<0|1>, 4: k_shade_quad<2>
+ * (the order of rt_stats.kernel_ms_by), -1: all). */
 typedef struct rt_work {
     uint64_t nodes_visited;
     uint64_t tris_tested;

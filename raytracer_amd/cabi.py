@@ -70,8 +70,8 @@ class rt_params(C.Structure):
 class rt_stats(C.Structure):
     _fields_ = [("trace_calls", C.c_uint64), ("shadow_rays", C.c_uint64),
                 ("level_rays", C.c_uint64 * 16), ("passes", C.c_uint32), ("retries", C.c_uint32),
-                ("kernel_ms", C.c_float), ("kernel_ms_by", C.c_float * 4),
-                ("kernel_launches_by", C.c_uint32 * 4), ("reserved", C.c_uint32)]
+                ("kernel_ms", C.c_float), ("kernel_ms_by", C.c_float * 5),
+                ("kernel_launches_by", C.c_uint32 * 5), ("reserved", C.c_uint32)]
 
 
 class rt_bvh_info(C.Structure):

@@ -49,14 +49,14 @@ struct PassCounters {                 // one per pass, zeroed by one memset per 
     uint32_t overflow;
     uint32_t pad[3];
     unsigned long long shadow[RT_STAT_SHARDS];
-    unsigned long long work[RT_WORK_SHARDS][4][12];   // per shard: RT_K_* kernels
+    unsigned long long work[RT_WORK_SHARDS][RT_N_KINDS][12];   // per shard: RT_K_* kernels
 };
 
 #define RT_MAX_PASSES 1024
 #define RT_PASS_SAMPLES (4u << 20)    // level-0 samples per pass
 #define RT_POOL_FACTOR 6u             // node pool = 6x the pass size when materials bounce (level 0 + 5x for deeper levels)
 #define RT_MAX_TIMED 2048
-enum { RT_K_EXTEND_WIDE = 0, RT_K_SHADE_WIDE = 1, RT_K_EXTEND_QUAD = 2, RT_K_SHADE_QUAD = 3 };
+enum { RT_K_EXTEND_WIDE = 0, RT_K_SHADE_WIDE = 1, RT_K_EXTEND_QUAD = 2, RT_K_SHADE_QUAD = 3, RT_K_SHADE_PARKED = 4 };
 #define RT_LEVEL_GRID 8192u           // workgroups of a level >= 1 launch (grid-stride over the device-side count)
 
 struct rt_scene {
@@ -88,7 +88,7 @@ struct rt_scene {
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     std::vector<hipEvent_t> ev_pool;
     bool count_work = false;
-    rt_work last_work[4]{};            // RT_K_* kernels
+    rt_work last_work[RT_N_KINDS]{};   // RT_K_* kernels
     int last_overflow = 0;
 };
 
@@ -256,7 +256,7 @@ static void add_work(rt_work& w, const unsigned long long* c) {
     w.wave_ticks_sum += c[10]; w.wave_ticks_max = std::max<uint64_t>(w.wave_ticks_max, c[11]);
 }
 extern "C" int rt_get_work(const rt_scene* s, int kernel, rt_work* out) {
-    if (!s || !out || kernel < -1 || kernel > 3) { rt_set_error("bad argument"); return RT_ERR_INVALID; }
+    if (!s || !out || kernel < -1 || kernel >= RT_N_KINDS) { rt_set_error("bad argument"); return RT_ERR_INVALID; }
     if (kernel >= 0) { *out = s->last_work[kernel]; return RT_OK; }
     *out = rt_work{};
     for (const rt_work& a : s->last_work) {
@@ -423,7 +423,7 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
             B.level = lo; B.level_hi = hi;
             const uint32_t g = form == RT_FORM_WIDE ? (hi == 0 ? grid0 : RT_LEVEL_GRID)
                                : (hi == 0 ? grid0q : (form == RT_FORM_QUAD_FRESH ? RT_LEVEL_GRID : 4u * RT_LEVEL_GRID));
-            return timed_launch(J, sb, form == RT_FORM_WIDE ? RT_K_SHADE_WIDE : RT_K_SHADE_QUAD,
+            return timed_launch(J, sb, form == RT_FORM_WIDE ? RT_K_SHADE_WIDE : form == RT_FORM_QUAD_PARKED ? RT_K_SHADE_PARKED : RT_K_SHADE_QUAD,
                                 [&] { launch_shade(form, s->count_work, s->d, B, g, sb); });
         };
         int small_lo = -1;      // first level of the run of small levels not shaded yet
@@ -445,9 +445,10 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
                     if ((rc = timed_launch(J, sa, RT_K_EXTEND_QUAD, [&] { launch_extend(src, RT_FORM_QUAD_RESUME, s->count_work, s->d, B, lv == 0 ? grid0q : 4u * RT_LEVEL_GRID, sa); })) != RT_OK) return rc;
                     if (overlap) HIP_TRY(hipEventRecord(s->ev_sync[2 * lv + 1], sa));
                 }
-                if ((rc = shade(RT_FORM_WIDE, lv, lv, 2 * lv)) != RT_OK) return rc;
+                const int ev_w = 2 * lv;
+                if ((rc = shade(RT_FORM_WIDE, lv, lv, ev_w)) != RT_OK) return rc;
                 if (meshes) {
-                    if ((rc = shade(RT_FORM_QUAD_RESUME, lv, lv, 2 * lv)) != RT_OK) return rc;
+                    if ((rc = shade(RT_FORM_QUAD_RESUME, lv, lv, ev_w)) != RT_OK) return rc;
                     if ((rc = shade(RT_FORM_QUAD_PARKED, lv, lv, 2 * lv + 1)) != RT_OK) return rc;
                 }
             } else {
@@ -558,15 +559,15 @@ static int render_frame(rt_scene* s, const rt_camera* cam, const rt_params* prm,
     if (stats) {
         HIP_TRY(hipEventRecord(s->ev_end, st));
         HIP_TRY(hipStreamSynchronize(st));
-        rt_work w[4]{};
+        rt_work w[RT_N_KINDS]{};
         for (const PassRec& r : final_recs) {
             const PassCounters& pc = s->h_counters[r.slot];
             // level 0: every valid sample is one trace() call; deeper levels: appended entries
             for (int k = 0; k < RT_STAT_SHARDS; ++k) stats->shadow_rays += pc.shadow[k];
             for (int lv = 1; lv < RT_MAX_LEVELS; ++lv) stats->level_rays[lv] += pc.level[lv] - pc.cancel[lv];
-            for (int sh = 0; sh < RT_WORK_SHARDS; ++sh) for (int k = 0; k < 4; ++k) add_work(w[k], pc.work[sh][k]);
+            for (int sh = 0; sh < RT_WORK_SHARDS; ++sh) for (int k = 0; k < RT_N_KINDS; ++k) add_work(w[k], pc.work[sh][k]);
         }
-        for (int k = 0; k < 4; ++k) s->last_work[k] = w[k];
+        for (int k = 0; k < RT_N_KINDS; ++k) s->last_work[k] = w[k];
         stats->passes = uint32_t(final_recs.size());
         stats->retries = retries;
         float ms = 0;
@@ -810,7 +811,7 @@ static int trace_chunk(rt_scene* s, const rt_params* prm, const float* d_rays, u
         for (int lv = 1; lv < RT_MAX_LEVELS; ++lv) stats->level_rays[lv] += pc.level[lv] - pc.cancel[lv];
         for (int k = 0; k < RT_STAT_SHARDS; ++k) stats->shadow_rays += pc.shadow[k];
         stats->passes += 1;
-        for (int sh = 0; sh < RT_WORK_SHARDS; ++sh) for (int k = 0; k < 4; ++k) add_work(s->last_work[k], pc.work[sh][k]);
+        for (int sh = 0; sh < RT_WORK_SHARDS; ++sh) for (int k = 0; k < RT_N_KINDS; ++k) add_work(s->last_work[k], pc.work[sh][k]);
     }
     return RT_OK;
 }

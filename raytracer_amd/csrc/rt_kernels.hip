@@ -565,7 +565,7 @@ __device__ __forceinline__ uint32_t rays_per_wave(uint32_t n_items) {
 }
 
 __device__ __forceinline__ void flush_work(unsigned long long* work, uint32_t kernel, const Work& wk) {
-    unsigned long long* out = work + ((blockIdx.x & (RT_WORK_SHARDS - 1)) * 4 + kernel) * 12;   // sharded like shadow_count
+    unsigned long long* out = work + ((blockIdx.x & (RT_WORK_SHARDS - 1)) * RT_N_KINDS + kernel) * 12;   // sharded like shadow_count
     const uint32_t a = wave_sum(wk.nodes), b = wave_sum(wk.tris), c = wave_sum(wk.spheres), d = wave_sum(wk.planes);
     const uint32_t e = wave_sum(wk.wave_nodes), f = wave_sum(wk.wave_tris);
     if (lane_id() == 0) {
@@ -949,7 +949,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade_quad(DScene S, LevelArgs A) 
                                n_shadow, parked);
     }
     flush_shadow(A, n_shadow);
-    if (COUNT) flush_work(A.work, 3, wk);
+    if (COUNT) flush_work(A.work, MODE == 2 ? 4 : 3, wk);
 }
 
 // Colour of pool node i once its children (one level deeper) are final.

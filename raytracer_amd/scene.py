@@ -359,8 +359,8 @@ class DeviceScene:
         cabi.check(self.lib, self.lib.rt_set_count_work(self.h, int(on)))
 
     def get_work(self, kernel=-1):
-        """Traversal work counters of the last counted call: kernel 0..3 = k_extend_wide, k_shade_wide, k_extend_quad,
-        k_shade_quad; -1 = all."""
+        """Traversal work counters of the last counted call: kernel 0..4 = k_extend_wide, k_shade_wide, k_extend_quad,
+        k_shade_quad<0|1>, k_shade_quad<2>; -1 = all."""
         w = cabi.rt_work()
         cabi.check(self.lib, self.lib.rt_get_work(self.h, int(kernel), C.byref(w)))
         return w

@@ -9,13 +9,13 @@ fs, cam, p = wl.make_workload(name)
 dev = DeviceScene(fs)
 dev.set_count_work(True)
 F = ["nodes_visited", "tris_tested", "wave_node_steps", "wave_tri_steps", "trav_ticks_sum", "batches", "trav_waves", "wave_ticks_sum"]
-prev = {k: np.zeros(len(F), np.int64) for k in range(4)}
+prev = {k: np.zeros(len(F), np.int64) for k in range(5)}
 prays = np.zeros(2, np.int64)
 for d in range(0, 3):
     pp = Params(max_depth=d, aa=p.aa)
     _, st = dev.render(cam, pp)
     rays = np.array([st.trace_calls, st.shadow_rays], np.int64)
-    for k, kn in ((0, "extend wide"), (2, "extend quad"), (1, "shade wide "), (3, "shade quad ")):
+    for k, kn in ((0, "extend wide"), (2, "extend quad"), (1, "shade wide "), (3, "shade quad "), (4, "shade park ")):
         w = dev.get_work(k)
         cur = np.array([getattr(w, f) for f in F], np.int64)
         dl = cur - prev[k]; prev[k] = cur

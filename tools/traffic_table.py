@@ -3,15 +3,15 @@ FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is doubled (gfx950 tallies 128-B 
 import csv, glob, json, re, sys, collections
 wl = sys.argv[1] if len(sys.argv) > 1 else "bunny_1080p"
 def short(n):
-    m = re.match(r'(?:void )?(k_\w+)', n)
-    return m.group(1) if m else n[:24]
+    m = re.match(r'(?:void )?(k_\w+)(<[^>]*>)?', n)     # kernel with its template arguments, as rocprofv3 names it
+    return (m.group(1) + (m.group(2) or '')) if m else n[:24]
 out = collections.defaultdict(lambda: {"launches": 0, "fetch_bytes": 0.0, "write_bytes": 0.0})
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(f'gpurun_out/pmc_{c}/**/p_counter_collection.csv', recursive=True)
     rows = [r for r in csv.DictReader(open(f[0])) if r['Counter_Name'] == c]
     ids = sorted({int(r['Dispatch_Id']) for r in rows})
     name = {int(r['Dispatch_Id']): short(r['Kernel_Name']) for r in rows}
-    res = [i for i in ids if name[i] == 'k_resolve']
+    res = [i for i in ids if name[i].startswith('k_resolve')]
     lo = res[-2] + 1
     seen = set()
     for r in rows:
