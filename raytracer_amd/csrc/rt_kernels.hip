@@ -5,17 +5,18 @@
 //   sphere_isect              Sphere::intersect + getNormal           reference src/primitives.cpp:173-203
 //   plane_isect               Plane::intersect                        reference src/primitives.cpp:11-25
 //   tri_isect                 Triangle::intersect (Moeller-Trumbore)  reference src/primitives.cpp:42-81,125
-//   model_closest / _any      Model::intersect                        reference src/primitives.cpp:364-384
-//   k_trace_level             trace(): closest hit, light loop, Fresnel, child rays   reference src/raytracer.cpp:279-396
+//   closest_loop / occluded_loop   the two object loops of trace()      reference src/raytracer.cpp:292-300, 319-325
+//   quad_traverse             the face loop of Model::intersect        reference src/primitives.cpp:364-384
+//   k_extend_wide / _quad     trace(): closest hit, Fresnel, child rays  reference src/raytracer.cpp:292-308, 347-396
+//   k_shade_wide / _quad      trace(): light loop (shadow test, Phong)   reference src/raytracer.cpp:311-345
 //   finish_color / k_fold     trace(): ambient + children + clamp     reference src/raytracer.cpp:399-406
 //   k_resolve                 render(): sample average + BGR8 quantisation  reference src/raytracer.cpp:436-448
 //
-// Structure (not the reference's): the recursion becomes level-synchronous. Level k's kernel takes every ray of
-// recursion depth k, finds its closest hit (objects in scene order; meshes through a BVH with an LDS stack), runs
-// the shadow tests and the Phong sums, writes one node record and appends the reflection / refraction child rays
-// to level k+1 with one atomic per wave (ballot + prefix count). Because the reference clamps the colour at EVERY
-// recursion level (raytracer.cpp:406) the tree is folded bottom-up afterwards, level by level, with exactly the
-// reference's expression per node; a throughput-product accumulator would be wrong.
+// Structure (not the reference's): the recursion becomes level-synchronous and every level is two independent stages,
+// extend and shade (see the comment above k_extend_wide). Child rays are appended to level k+1 with one atomic per
+// wave (ballot + prefix count). Because the reference clamps the colour at EVERY recursion level (raytracer.cpp:406)
+// the tree is folded bottom-up afterwards, level by level, with exactly the reference's expression per node; a
+// throughput-product accumulator would be wrong.
 //
 // Arithmetic: IEEE binary32 with the reference's operation order, compiled with -ffp-contract=off (no FMA
 // contraction; the x86 reference build has none), correctly rounded f32 divide/sqrt (hipcc default), and double
@@ -526,12 +527,12 @@ __device__ __forceinline__ bool map_pixel(const PixelMap& pm, uint64_t q, uint32
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// One recursion level of trace() is two kernels:
-//   k_extend  closest hit of every ray of the level (raytracer.cpp:292-308), Fresnel term and the child rays
+// One recursion level of trace() is two stages, each in a per-lane ("wide") and a per-quad kernel:
+//   extend    closest hit of every ray of the level (raytracer.cpp:292-308), Fresnel term and the child rays
 //             (raytracer.cpp:347-396) appended to level+1. Needs ~half the registers of a fused kernel.
-//   k_shade   the light loop (raytracer.cpp:311-345) for the hits of one or several levels. Nothing downstream of
-//             k_extend waits for it, so the host runs it on a second stream, next to k_extend of the deeper levels:
-//             the dependent chain of a level is ONE traversal instead of 1 + n_lights.
+//   shade     the light loop (raytracer.cpp:311-345) for the hits of one or several levels. Nothing downstream of
+//             extend waits for it, so the host runs it on other streams, next to the extend kernels of the deeper
+//             levels: the dependent chain of a level is ONE traversal instead of 1 + n_lights.
 // The `return red` exit (raytracer.cpp:330-332) is decided by k_shade, after the children were appended: a hit with a
 // NaN normal has at most one child, the reflection ray, whose direction is all NaN; such a ray misses every primitive
 // (all comparisons false) and shoots no shadow rays, so it costs one wasted background node. k_shade then clears
