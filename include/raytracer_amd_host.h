@@ -50,6 +50,18 @@ void rt_host_model_free(rt_host_model* m);
  * [15] cos(cross.e1). */
 int rt_host_known_answers(float* out16);
 
+/* Scene::Scene(filename) (reference src/scene.cpp:32-189: colors, materials, lights, primitives of a scene.yaml;
+ * meshes go through load_ply + the transform chain), without OpenCV. The flat view (object order = file order)
+ * stays valid until rt_host_scene_free and can be passed to rt_scene_create as it is. */
+typedef struct rt_host_scene rt_host_scene;
+int rt_host_scene_load_yaml(const char* fname, rt_host_scene** out);
+const rt_flat_scene* rt_host_scene_flat(const rt_host_scene* scene);
+void rt_host_scene_free(rt_host_scene* scene);
+
+/* cv::imwrite(outFilename, img) of main() (reference src/raytracer.cpp:720) for the BGR8 frame rt_render fills:
+ * .png (8-bit RGB, uncompressed deflate) or .ppm (P6). */
+int rt_host_write_image(const char* fname, const uint8_t* bgr, uint32_t W, uint32_t H);
+
 #ifdef __cplusplus
 }
 #endif

@@ -106,7 +106,7 @@ EXPORTS = [
 HOST_EXPORTS = [
     "rt_host_camera_make", "rt_host_plane_make", "rt_host_mat3_rotation", "rt_host_bbvol", "rt_host_model_load_ply",
     "rt_host_model_transform", "rt_host_model_num_faces", "rt_host_model_get", "rt_host_model_free",
-    "rt_host_known_answers",
+    "rt_host_known_answers", "rt_host_scene_load_yaml", "rt_host_scene_flat", "rt_host_scene_free", "rt_host_write_image",
 ]
 
 _lib = None

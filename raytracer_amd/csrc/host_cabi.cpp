@@ -3,6 +3,8 @@
 #include "raytracer_amd_host.h"
 
 #include "../host/raytracer.hpp"
+#include "../host/scene_yaml.hpp"
+#include "../host/image_io.hpp"
 
 void rt_set_error(const char* fmt, ...);   // rt_api.cpp
 
@@ -13,6 +15,12 @@ void put(float* d, const Vec3f& v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; }
 
 struct rt_host_model {
     std::unique_ptr<Model> m;
+};
+
+struct rt_host_scene {
+    std::unique_ptr<Scene> scene;
+    FlatSceneBuilder fb;
+    rt_flat_scene view;
 };
 
 extern "C" {
@@ -111,5 +119,37 @@ int rt_host_known_answers(float* out) {
     out[15] = float(std::cos(double(cp.dotProduct(Vec3f(1, 0, 0)))));
     return RT_OK;
 }
+
+
+int rt_host_scene_load_yaml(const char* fname, rt_host_scene** out) {
+    if (!fname || !out) { rt_set_error("rt_host_scene_load_yaml: null argument"); return RT_ERR_INVALID; }
+    *out = nullptr;
+    try {
+        std::unique_ptr<rt_host_scene> h(new rt_host_scene());
+        h->scene.reset(new Scene(std::string(fname)));
+        h->scene->flatten(h->fb);
+        h->view = h->fb.view();
+        *out = h.release();
+    } catch (const std::exception& e) {
+        rt_set_error("%s", e.what());
+        return RT_ERR_INVALID;
+    }
+    return RT_OK;
+}
+
+int rt_host_write_image(const char* fname, const uint8_t* bgr, uint32_t W, uint32_t H) {
+    if (!fname || !bgr) { rt_set_error("rt_host_write_image: null argument"); return RT_ERR_INVALID; }
+    try {
+        write_image(fname, bgr, W, H);
+    } catch (const std::exception& e) {
+        rt_set_error("%s", e.what());
+        return RT_ERR_INVALID;
+    }
+    return RT_OK;
+}
+
+const rt_flat_scene* rt_host_scene_flat(const rt_host_scene* s) { return s ? &s->view : nullptr; }
+
+void rt_host_scene_free(rt_host_scene* s) { delete s; }
 
 }  // extern "C"

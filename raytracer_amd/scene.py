@@ -34,8 +34,21 @@ def host_lib():
         lib.rt_host_model_free.argtypes = [C.c_void_p]
         lib.rt_host_model_free.restype = None
         lib.rt_host_known_answers.argtypes = [FP]
+        lib.rt_host_scene_load_yaml.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        lib.rt_host_scene_flat.argtypes = [C.c_void_p]
+        lib.rt_host_scene_flat.restype = C.POINTER(rt_flat_scene)
+        lib.rt_host_scene_free.argtypes = [C.c_void_p]
+        lib.rt_host_scene_free.restype = None
+        lib.rt_host_write_image.argtypes = [C.c_char_p, C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32]
         _host_bound = True
     return lib
+
+
+def write_image(path, frame):
+    """cv::imwrite of the reference's main() (src/raytracer.cpp:720) for an (H,W,3) BGR8 frame: .png or .ppm."""
+    frame = np.ascontiguousarray(frame, dtype=np.uint8)
+    lib = host_lib()
+    cabi.check(lib, lib.rt_host_write_image(str(path).encode(), cabi.u8ptr(frame), frame.shape[1], frame.shape[0]))
 
 
 def _f3(v):
@@ -244,6 +257,41 @@ class FlatScene:
             l.color[:] = [float(x) for x in r[3:]]
             fs.lights.append(l)
         return fs
+
+    @staticmethod
+    def load_yaml(path):
+        """Scene::Scene(filename) of the C++ host surface (reference src/scene.cpp:32-189, OpenCV-free): a scene.yaml
+        with its meshes loaded and transformed, as a FlatScene in file order."""
+        lib = host_lib()
+        h = C.c_void_p()
+        cabi.check(lib, lib.rt_host_scene_load_yaml(str(path).encode(), C.byref(h)))
+        try:
+            c = lib.rt_host_scene_flat(h).contents
+            nf = c.n_faces
+
+            def tri(ptr):
+                return np.ctypeslib.as_array(ptr, shape=(nf * 3,)).reshape(nf, 3).copy() if nf else np.zeros((0, 3), np.float32)
+            d = {
+                "objects": np.array([[c.objects[i].type, c.objects[i].index, c.objects[i].material]
+                                     for i in range(c.n_objects)], dtype=np.int64).reshape(-1, 3),
+                "spheres": np.array([[*c.spheres[i].center, c.spheres[i].radius] for i in range(c.n_spheres)],
+                                    dtype=np.float32).reshape(-1, 4),
+                "planes": np.array([[c.planes[i].a, c.planes[i].b, c.planes[i].c, c.planes[i].d]
+                                    for i in range(c.n_planes)], dtype=np.float32).reshape(-1, 4),
+                "materials": np.array([[*c.materials[i].color, c.materials[i].ka, c.materials[i].kd, c.materials[i].ks,
+                                        c.materials[i].kr, c.materials[i].kt, c.materials[i].specRefExp,
+                                        c.materials[i].refractiveIdx, c.materials[i].reflective, c.materials[i].refractive]
+                                       for i in range(c.n_materials)], dtype=np.float32).reshape(-1, 12),
+                "lights": np.array([[*c.lights[i].pos, *c.lights[i].color] for i in range(c.n_lights)],
+                                   dtype=np.float32).reshape(-1, 6),
+                "mesh_faces": np.array([c.models[i].num_faces for i in range(c.n_models)], dtype=np.int64),
+                "mesh_bb": np.array([[*c.models[i].bb_center, c.models[i].bb_radius] for i in range(c.n_models)],
+                                    dtype=np.float32).reshape(-1, 4),
+                "v0": tri(c.v0), "v1": tri(c.v1), "v2": tri(c.v2), "n0": tri(c.n0), "n1": tri(c.n1), "n2": tri(c.n2),
+            }
+        finally:
+            lib.rt_host_scene_free(h)
+        return FlatScene.from_arrays(d)
 
     def c_struct(self):
         if self._c is not None:

@@ -6,6 +6,7 @@ import ctypes as C
 import os
 
 import numpy as np
+import pytest
 
 from helpers import gold, same_bits
 from raytracer_amd import cabi
@@ -105,3 +106,38 @@ def test_scene_create_needs_a_gpu_or_fails_loudly():
         assert "rt error" in str(e)
     else:
         raise AssertionError("rt_scene_create succeeded without a GPU")
+
+
+def test_write_image_png_and_ppm(tmp_path):
+    """write_image (host surface, replaces cv::imwrite of main()): the PNG decodes (zlib + CRCs) to the frame's RGB
+    bytes, the PPM holds them verbatim."""
+    import struct
+    import zlib
+    from raytracer_amd.scene import write_image
+    rng = np.random.default_rng(5)
+    frame = rng.integers(0, 256, (37, 301, 3), dtype=np.uint8)        # BGR, more than one 64-KiB deflate block
+    rgb = frame[:, :, ::-1]
+    png, ppm = tmp_path / "f.png", tmp_path / "f.ppm"
+    write_image(png, frame)
+    write_image(ppm, frame)
+    b = png.read_bytes()
+    assert b[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, seen = 8, b"", []
+    while pos < len(b):
+        n, typ = struct.unpack(">I4s", b[pos:pos + 8])
+        data = b[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", b[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(typ + data)
+        seen.append(typ)
+        if typ == b"IHDR":
+            assert struct.unpack(">IIBBBBB", data) == (301, 37, 8, 2, 0, 0, 0)
+        if typ == b"IDAT":
+            idat += data
+        pos += 12 + n
+    assert seen == [b"IHDR", b"IDAT", b"IEND"]
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(37, 1 + 301 * 3)
+    assert not raw[:, 0].any() and np.array_equal(raw[:, 1:].reshape(37, 301, 3), rgb)
+    p = ppm.read_bytes()
+    head = b"P6\n301 37\n255\n"
+    assert p.startswith(head) and np.array_equal(np.frombuffer(p[len(head):], np.uint8).reshape(37, 301, 3), rgb)
+    with pytest.raises(Exception):
+        write_image(tmp_path / "f.jpg", frame)
