@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal only: every rank uses GPU 0 (needs --backend gloo)")
+    ap.add_argument("--frames-in-flight", type=int, default=2,
+                    help="frames rendered concurrently (each in its own scene workspace and stream); 1 = one at a time")
     ap.add_argument("--watchdog", type=int, default=0, help="dump all Python stacks and exit after this many seconds")
     args = ap.parse_args()
     if args.watchdog:
@@ -117,8 +119,28 @@ def main():
     build_s = time.time() - t0
     lib = dev.lib
     W, H = cam.imWidth, cam.imHeight
-    stream = torch.cuda.current_stream().cuda_stream
-    frame = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+    tw = th = args.tile
+
+    # Frames in flight. A frame ends in a chain of small, latency-bound launches (deep bounce levels, fold) that leave
+    # most of the chip idle; with a second frame in flight (its own scene workspace, stream and framebuffer) that tail
+    # overlaps the next frame's large levels. Every frame is still rendered completely and checked below.
+    class Slot:
+        pass
+    slots = []
+    for k in range(max(1, args.frames_in_flight)):
+        sl = Slot()
+        sl.dev = dev if k == 0 else DeviceScene(fs, device=local)
+        # the scene's own stream, seen by torch: renders, the RCCL gather and the untile are ordered on it
+        sl.stream = torch.cuda.ExternalStream(sl.dev.stream(), device=torch.device("cuda", local))
+        sl.frame = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+        if world > 1:
+            sl.n_slot = lib.rt_tiles_owned(W, H, tw, th, 0, world)       # part 0 owns the most tiles
+            sl.mine = torch.zeros((sl.n_slot * tw * th * 3,), dtype=torch.uint8, device="cuda")
+            sl.allt = torch.zeros((world * sl.n_slot * tw * th * 3,), dtype=torch.uint8, device="cuda") if rank == 0 else None
+            sl.gathered = list(sl.allt.chunk(world)) if rank == 0 else None     # the gather lands directly in the untile input
+        slots.append(sl)
+    stream = slots[0].stream.cuda_stream
+    frame = slots[0].frame
 
     # ray census of one frame (untimed), with the traversal work counters on
     st = rt_stats()
@@ -132,43 +154,38 @@ def main():
         ref_frame = frame.clone()
     rays_per_frame = st.trace_calls + st.shadow_rays
 
-    tw = th = args.tile
-    if world > 1:
-        owned = lib.rt_tiles_owned(W, H, tw, th, rank, world)
-        slot = lib.rt_tiles_owned(W, H, tw, th, 0, world)       # part 0 owns the most tiles
-        mine = torch.zeros((slot * tw * th * 3,), dtype=torch.uint8, device="cuda")
-        allt = torch.zeros((world * slot * tw * th * 3,), dtype=torch.uint8, device="cuda") if rank == 0 else None
-        gathered = list(allt.chunk(world)) if rank == 0 else None     # the gather lands directly in the untile input
-
-    def step():
-        if world == 1:
-            dev.render_device(cam, params, frame.data_ptr(), stream=stream)
-        else:
-            dev.render_tiles_device(cam, params, (tw, th), rank, world, mine.data_ptr(), stream=stream)
+    def step(i):
+        sl = slots[i % len(slots)]
+        h = sl.stream.cuda_stream
+        with torch.cuda.stream(sl.stream):
+            if world == 1:
+                sl.dev.render_device(cam, params, sl.frame.data_ptr(), stream=h)
+                return
+            sl.dev.render_tiles_device(cam, params, (tw, th), rank, world, sl.mine.data_ptr(), stream=h)
             if args.backend == "nccl":
-                dist.gather(mine, gathered, dst=0)
+                dist.gather(sl.mine, sl.gathered, dst=0)
             else:       # gloo rehearsal: gloo gathers host tensors only
-                torch.cuda.synchronize()        # the render runs on the scene's own stream when `stream` is the null stream
-                host = mine.cpu()
+                sl.stream.synchronize()
+                host = sl.mine.cpu()
                 hg = [torch.zeros_like(host) for _ in range(world)] if rank == 0 else None
                 dist.gather(host, hg, dst=0)
                 if rank == 0:
-                    allt.copy_(torch.cat(hg))
+                    sl.allt.copy_(torch.cat(hg))
             if rank == 0:
-                cabi.check(lib, lib.rt_untile_device(local, W, H, tw, th, world, slot, C.c_void_p(allt.data_ptr()),
-                                                     C.c_void_p(frame.data_ptr()), C.c_void_p(stream)))
+                cabi.check(lib, lib.rt_untile_device(local, W, H, tw, th, world, sl.n_slot, C.c_void_p(sl.allt.data_ptr()),
+                                                     C.c_void_p(sl.frame.data_ptr()), C.c_void_p(h)))
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
     sync()
     t = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        step(i)
     sync()
     elapsed = time.perf_counter() - t
     if world > 1:
@@ -192,8 +209,18 @@ def main():
                        "mesh": "procedural geodesic blob (no .ply ships with the reference)",
                        "scene_build_s": round(build_s, 3)},
         }
-        identical = bool(torch.equal(frame, ref_frame))
+        used = slots[:min(len(slots), args.steps + args.warmup)]
+        identical = all(bool(torch.equal(sl.frame, ref_frame)) for sl in used)
         out["frame_identical_to_1gpu"] = identical
+        out["config"]["frames_in_flight"] = len(slots)
+        if world == 1 and len(slots) > 1:
+            # latency view: the same frames one at a time (one workspace, one stream)
+            t = time.perf_counter()
+            for _ in range(args.steps):
+                with torch.cuda.stream(slots[0].stream):
+                    dev.render_device(cam, params, frame.data_ptr(), stream=stream)
+            torch.cuda.synchronize()
+            out["one_frame_at_a_time"] = {"ms_per_frame": (time.perf_counter() - t) / args.steps * 1e3}
         if world == 1:
             # The frame's time is in four kernels: k_extend_wide / k_extend_quad (closest hits: analytic objects one ray
             # per lane, meshes one ray per quad) and k_shade_wide / k_shade_quad (shadow rays + Phong). A call with stats

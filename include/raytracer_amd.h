@@ -157,6 +157,11 @@ int rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_params* par
                      uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
                      uint8_t* d_bgr_out, void* stream, rt_stats* stats);
 
+/* The scene's own stream (a hipStream_t): the one asynchronous calls use when `stream` is NULL. Callers that have
+ * to order other work behind a frame (a collective, a copy) enqueue it there or wait for an event recorded there.
+ * No counterpart in the reference (its render() is synchronous). */
+void* rt_scene_stream(const rt_scene* scene);
+
 /* Multi-GPU tile ownership. Replaces: the tile decomposition of thread_render()
  * (reference src/raytracer.cpp:577-627: fixed tiles handed to workers). The full image is cut into
  * tile_w x tile_h tiles, numbered row-major; this call renders the tiles with

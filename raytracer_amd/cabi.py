@@ -100,7 +100,7 @@ def u8ptr(a):
 EXPORTS = [
     "rt_scene_create", "rt_scene_destroy", "rt_render", "rt_render_device", "rt_render_tiles_device",
     "rt_tiles_owned", "rt_untile_device", "rt_cast_rays", "rt_intersect", "rt_occluded", "rt_trace",
-    "rt_scene_bvh_info", "rt_set_count_work", "rt_get_work", "rt_last_error", "rt_version",
+    "rt_scene_bvh_info", "rt_scene_stream", "rt_set_count_work", "rt_get_work", "rt_last_error", "rt_version",
 ]
 
 HOST_EXPORTS = [
@@ -143,6 +143,8 @@ def load(path=None):
     lib.rt_occluded.argtypes = [vp, FP, FP, u32, C.POINTER(C.c_uint8)]
     lib.rt_trace.argtypes = [vp, C.POINTER(rt_params), FP, u32, FP, C.POINTER(rt_stats)]
     lib.rt_scene_bvh_info.argtypes = [vp, C.POINTER(rt_bvh_info)]
+    lib.rt_scene_stream.argtypes = [vp]
+    lib.rt_scene_stream.restype = C.c_void_p
     lib.rt_set_count_work.argtypes = [vp, C.c_int]
     lib.rt_get_work.argtypes = [vp, C.c_int, C.POINTER(rt_work)]
     lib.rt_last_error.restype = C.c_char_p

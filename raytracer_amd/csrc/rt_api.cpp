@@ -235,6 +235,8 @@ extern "C" int rt_scene_create(const rt_flat_scene* sc, int device, rt_scene** o
 
 extern "C" void rt_scene_destroy(rt_scene* s) { free_scene(s); }
 
+extern "C" void* rt_scene_stream(const rt_scene* s) { return s ? static_cast<void*>(s->stream) : nullptr; }
+
 extern "C" int rt_scene_bvh_info(const rt_scene* s, rt_bvh_info* out) {
     if (!s || !out) { rt_set_error("null argument"); return RT_ERR_INVALID; }
     out->n_nodes = s->n_nodes; out->n_faces = s->n_faces; out->max_depth = s->bvh_depth;

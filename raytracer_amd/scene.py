@@ -403,6 +403,10 @@ class DeviceScene:
         cabi.check(self.lib, self.lib.rt_scene_bvh_info(self.h, C.byref(info)))
         return info
 
+    def stream(self):
+        """The scene's own hipStream_t (integer handle), used by asynchronous calls when no stream is passed."""
+        return self.lib.rt_scene_stream(self.h)
+
     def set_count_work(self, on):
         cabi.check(self.lib, self.lib.rt_set_count_work(self.h, int(on)))
 
