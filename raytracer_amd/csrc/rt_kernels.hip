@@ -593,7 +593,14 @@ __device__ __forceinline__ bool fetch_ray(const LevelArgs& A, uint32_t begin, ui
         const uint64_t g = A.sample0 + (i - begin);
         uint32_t x, y; uint64_t off; bool inb;
         if (!map_pixel(A.pm, g / A.spp, x, y, off, inb)) return false;
-        ray = cast_ray(A.cam, A.aa, x, y, (uint32_t)(g % A.spp));
+        DCamera cam;                                                      // wave-uniform: scalar loads
+        {
+            const RT_CONSTANT uint32_t* src = (const RT_CONSTANT uint32_t*)(const void*)(&A.fp->cam);
+            uint32_t* dst = reinterpret_cast<uint32_t*>(&cam);
+#pragma unroll
+            for (int k = 0; k < (int)(sizeof(DCamera) / 4); ++k) dst[k] = src[k];
+        }
+        ray = cast_ray(cam, A.aa, x, y, (uint32_t)(g % A.spp));
     } else if (SRC == 1) {
         const float4 o = A.rays[2 * (size_t)(i - A.n0)], d = A.rays[2 * (size_t)(i - A.n0) + 1];
         ray.o = f4xyz(o); ray.d = f4xyz(d);
@@ -691,7 +698,8 @@ __device__ __forceinline__ void extend_finish(const DScene& S, const LevelArgs& 
             A.hit_n[i] = make_float4(h.n.x, h.n.y, h.n.z, h.tmpdist);
             A.hit_p[i] = make_float4(hitPt.x, hitPt.y, hitPt.z, rCoef);
         } else if (rec_b.w & NODE_VALID) {
-            A.node_a[i] = make_float4(A.background[0], A.background[1], A.background[2], 0);   // raytracer.cpp:302-304
+            const u32x4 bg = ldc4(A.fp->background, 0);
+            A.node_a[i] = make_float4(__uint_as_float(bg.x), __uint_as_float(bg.y), __uint_as_float(bg.z), 0);   // raytracer.cpp:302-304
         } else {
             A.node_a[i] = make_float4(0, 0, 0, 0);
         }
@@ -966,6 +974,11 @@ __device__ __forceinline__ V3 node_color(const DScene& S, const float4* __restri
     return finish_color(mk(a.x, a.y, a.z), m, a.w, refl, refr);
 }
 
+// Frame parameters by value -> device memory (one tiny launch per frame; see FrameParams).
+__global__ void k_set_frame_params(FrameParams p, FrameParams* dst) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *dst = p;
+}
+
 // Fold of one level (>= 1): finishes every node whose children were traced one level deeper.
 __global__ __launch_bounds__(256) void k_fold(DScene S, LevelArgs A) {
     uint32_t begin, end;
@@ -1147,6 +1160,9 @@ void launch_shade(int form, bool count, const DScene& S, const LevelArgs& A, uin
         if (count) hipLaunchKernelGGL((k_shade_quad<2, true>), g, b, 0, st, S, A);
         else hipLaunchKernelGGL((k_shade_quad<2, false>), g, b, 0, st, S, A);
     }
+}
+void launch_set_frame_params(const FrameParams& p, FrameParams* dst, hipStream_t st) {
+    hipLaunchKernelGGL(k_set_frame_params, dim3(1), dim3(64), 0, st, p, dst);
 }
 void launch_fold(const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st) {
     hipLaunchKernelGGL(k_fold, dim3(grid), dim3(256), 0, st, S, A);

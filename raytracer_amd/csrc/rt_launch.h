@@ -51,6 +51,14 @@ struct PixelMap {
 //   k_extend writes  node_b (children, material, flags), hit_n, hit_p for a hit; node_a for a miss
 //   k_shade  writes  node_a for a hit (light loop of trace()), may downgrade node_b.w (the `return red` exit)
 //   k_fold / k_resolve read node_a / node_b
+// What changes from frame to frame at a fixed resolution: it lives in device memory (written by k_set_frame_params at
+// the start of every frame) so that the launches of a frame do not depend on it and can be replayed as a hipGraph.
+struct FrameParams {
+    float background[3];
+    float pad;
+    DCamera cam;
+};
+
 struct LevelArgs {
     uint32_t n0;                 // level-0 samples of this pass (multiple of spp)
     int32_t level;               // k_extend / k_fold: the level; k_shade: first level of the range
@@ -76,11 +84,11 @@ struct LevelArgs {
     uint32_t* qcount_s;
     const float* aa;             // anti-aliasing pattern (device)
     const float* user_rays;      // SRC 2
-    float background[3];
+    const FrameParams* fp;       // camera + background of the frame (device)
     uint32_t debug;              // timing experiments only (RT_DEBUG_SKIP)
+    uint32_t pad2;
     uint4* wave_log;             // diagnostics (COUNT builds, RT_WAVE_LOG): per workgroup {start, end, traversal ticks, batches}
     PixelMap pm;
-    DCamera cam;
 };
 
 struct UntileArgs {
@@ -93,6 +101,7 @@ struct UntileArgs {
 enum { RT_FORM_WIDE = 0, RT_FORM_QUAD_FRESH = 1, RT_FORM_QUAD_RESUME = 2, RT_FORM_QUAD_PARKED = 3 };
 void launch_extend(int src, int form, bool count, const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st);
 void launch_shade(int form, bool count, const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st);
+void launch_set_frame_params(const FrameParams& p, FrameParams* dst, hipStream_t st);
 void launch_fold(const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st);
 void launch_resolve(const DScene& S, const LevelArgs& A, uint8_t* out, hipStream_t st);
 void launch_resolve_rgb(const DScene& S, const LevelArgs& A, float* rgb, hipStream_t st);
