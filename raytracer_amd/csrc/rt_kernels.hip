@@ -995,6 +995,28 @@ __global__ __launch_bounds__(256) void k_fold(DScene S, LevelArgs A) {
     }
 }
 
+// Fold of levels A.level_hi down to A.level by ONE workgroup: one launch instead of one per level, for frames whose
+// cost is the host's launch rate (deep levels hold few nodes). A level's writes are visible to the next iteration
+// after the barrier: the workgroup's waves share an L1.
+__global__ __launch_bounds__(1024) void k_fold_tail(DScene S, LevelArgs A) {
+    for (int lv = A.level_hi; lv >= A.level; --lv) {
+        uint32_t begin, end;
+        level_range(A, lv, lv, begin, end);
+        for (uint32_t i = begin + threadIdx.x; i < end; i += 1024) {
+            const uint4 b = A.node_b[i];
+            if (b.w & NODE_FOLD) {
+                const V3 c = node_color(S, A.node_a, A.node_b, i);
+                float4 a = A.node_a[i];
+                a.x = c.x; a.y = c.y; a.z = c.z;
+                A.node_a[i] = a;
+                A.node_b[i].w = b.w & ~NODE_FOLD;
+            }
+        }
+        __threadfence();
+        __syncthreads();
+    }
+}
+
 // render(): px += trace(...) / numRays per sample, then (uchar)(c*255) as B,G,R (reference src/raytracer.cpp:436-448).
 // One thread per pixel of the pass; level-0 nodes of a pixel are consecutive.
 __global__ __launch_bounds__(256) void k_resolve(DScene S, LevelArgs A, uint8_t* __restrict__ out) {
@@ -1166,6 +1188,9 @@ void launch_set_frame_params(const FrameParams& p, FrameParams* dst, hipStream_t
 }
 void launch_fold(const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st) {
     hipLaunchKernelGGL(k_fold, dim3(grid), dim3(256), 0, st, S, A);
+}
+void launch_fold_tail(const DScene& S, const LevelArgs& A, hipStream_t st) {
+    hipLaunchKernelGGL(k_fold_tail, dim3(1), dim3(1024), 0, st, S, A);
 }
 void launch_resolve(const DScene& S, const LevelArgs& A, uint8_t* out, hipStream_t st) {
     const uint32_t npix = A.n0 / A.spp;

@@ -103,6 +103,7 @@ void launch_extend(int src, int form, bool count, const DScene& S, const LevelAr
 void launch_shade(int form, bool count, const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st);
 void launch_set_frame_params(const FrameParams& p, FrameParams* dst, hipStream_t st);
 void launch_fold(const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st);
+void launch_fold_tail(const DScene& S, const LevelArgs& A, hipStream_t st);   // levels A.level..A.level_hi, one workgroup
 void launch_resolve(const DScene& S, const LevelArgs& A, uint8_t* out, hipStream_t st);
 void launch_resolve_rgb(const DScene& S, const LevelArgs& A, float* rgb, hipStream_t st);
 void launch_untile(const UntileArgs& U, const uint8_t* tiles, uint8_t* out, hipStream_t st);
