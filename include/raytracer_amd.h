@@ -217,6 +217,19 @@ typedef struct rt_bvh_info {
 } rt_bvh_info;
 int rt_scene_bvh_info(const rt_scene* scene, rt_bvh_info* out);
 
+/* Builds the scene's BVHs on the host only (no GPU is touched) and walks them: every face of a model in exactly one
+ * leaf block, leaf data equal to the v0 / v1-v0 / v2-v0 floats Triangle::intersect forms (reference
+ * src/primitives.cpp:52-53), every child box containing the vertices below it, children packed to the front, stack
+ * bound within the traversal's. `errors` counts violations (0 = sound). No counterpart in the reference (it has no
+ * acceleration structure); used by the CPU tests and to time the builder. */
+typedef struct rt_bvh_check_result {
+    uint32_t n_nodes, n_leaves, n_faces, max_depth, max_stack, reserved;
+    uint64_t errors;
+    uint64_t host_bytes;     /* nodes + leaf blocks */
+    double build_seconds;
+} rt_bvh_check_result;
+int rt_bvh_check(const rt_flat_scene* scene, rt_bvh_check_result* out);
+
 /* Traversal work of the last call that passed a non-NULL stats AND had counting enabled with
  * rt_set_count_work(1): node visits / triangle tests / sphere / plane tests summed over all rays, per kernel:
  * rt_get_work(kernel = 0: k_extend_wide, 1: k_shade_wide, 2: k_extend_quad, 3: k_shade_quad<0|1>, 4: k_shade_quad<2>

@@ -32,6 +32,13 @@ typedef struct rt_host_model rt_host_model;
 /* Replaces: Model::load_ply(fname, material, calcNormal=true) (reference src/primitives.cpp:238-362). */
 int rt_host_model_load_ply(const char* fname, rt_host_model** out);
 
+/* Replaces: the part of Model::load_ply after the text is parsed (reference src/primitives.cpp:287-362:
+ * re-centre on the vertex mean, per-vertex normals, faces), for meshes that are already in memory
+ * (vertices: n_vertices*3 floats, indices: n_faces*3). Same result as writing the arrays as an ASCII .ply with
+ * 9 significant digits and calling rt_host_model_load_ply. */
+int rt_host_model_from_arrays(const float* vertices, uint32_t n_vertices, const uint32_t* indices,
+                              uint32_t n_faces, rt_host_model** out);
+
 /* Replaces: the mesh branch of the scene loader (reference src/scene.cpp:161-163):
  * model *= Mat3d::rotation(rot); model.scale(scale); model += translation. */
 int rt_host_model_transform(rt_host_model* m, const float* rot, double scale, const float* translation);

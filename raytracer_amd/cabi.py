@@ -80,6 +80,12 @@ class rt_bvh_info(C.Structure):
                 ("device_bytes", C.c_uint64)]
 
 
+class rt_bvh_check_result(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint32), ("n_leaves", C.c_uint32), ("n_faces", C.c_uint32),
+                ("max_depth", C.c_uint32), ("max_stack", C.c_uint32), ("reserved", C.c_uint32),
+                ("errors", C.c_uint64), ("host_bytes", C.c_uint64), ("build_seconds", C.c_double)]
+
+
 class rt_work(C.Structure):
     _fields_ = [("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64),
                 ("spheres_tested", C.c_uint64), ("planes_tested", C.c_uint64),
@@ -100,12 +106,12 @@ def u8ptr(a):
 EXPORTS = [
     "rt_scene_create", "rt_scene_destroy", "rt_render", "rt_render_device", "rt_render_tiles_device",
     "rt_tiles_owned", "rt_untile_device", "rt_cast_rays", "rt_intersect", "rt_occluded", "rt_trace",
-    "rt_scene_bvh_info", "rt_scene_stream", "rt_set_count_work", "rt_get_work", "rt_last_error", "rt_version",
+    "rt_scene_bvh_info", "rt_bvh_check", "rt_scene_stream", "rt_set_count_work", "rt_get_work", "rt_last_error", "rt_version",
 ]
 
 HOST_EXPORTS = [
     "rt_host_camera_make", "rt_host_plane_make", "rt_host_mat3_rotation", "rt_host_bbvol", "rt_host_model_load_ply",
-    "rt_host_model_transform", "rt_host_model_num_faces", "rt_host_model_get", "rt_host_model_free",
+    "rt_host_model_from_arrays", "rt_host_model_transform", "rt_host_model_num_faces", "rt_host_model_get", "rt_host_model_free",
     "rt_host_known_answers", "rt_host_scene_load_yaml", "rt_host_scene_flat", "rt_host_scene_free", "rt_host_write_image",
 ]
 
@@ -143,6 +149,7 @@ def load(path=None):
     lib.rt_occluded.argtypes = [vp, FP, FP, u32, C.POINTER(C.c_uint8)]
     lib.rt_trace.argtypes = [vp, C.POINTER(rt_params), FP, u32, FP, C.POINTER(rt_stats)]
     lib.rt_scene_bvh_info.argtypes = [vp, C.POINTER(rt_bvh_info)]
+    lib.rt_bvh_check.argtypes = [C.POINTER(rt_flat_scene), C.POINTER(rt_bvh_check_result)]
     lib.rt_scene_stream.argtypes = [vp]
     lib.rt_scene_stream.restype = C.c_void_p
     lib.rt_set_count_work.argtypes = [vp, C.c_int]

@@ -11,11 +11,13 @@
 // Moeller-Trumbore test accepts slightly outside the exact triangle is still inside its leaf box.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
 
+#include "raytracer_amd.h"
 #include "rt_device.h"
 
 namespace {
@@ -183,7 +185,9 @@ struct Builder {
         int axis = 0;
         float ext = -1;
         for (int a = 0; a < 3; ++a) if (bx.hi[a] - bx.lo[a] > ext) { ext = bx.hi[a] - bx.lo[a]; axis = a; }
-        const uint32_t mid = b + (e - b) / 2;
+        uint32_t half = ((e - b) / 2 + RT_MAX_LEAF_TRIS - 1) / RT_MAX_LEAF_TRIS * RT_MAX_LEAF_TRIS;   // keeps leaves full
+        if (half >= e - b) half = (e - b) / 2;
+        const uint32_t mid = b + half;
         std::nth_element(order.begin() + b, order.begin() + mid, order.begin() + e, [&](uint32_t x, uint32_t y) {
             const float cx = centroid[3 * size_t(x) + axis], cy = centroid[3 * size_t(y) + axis];
             return cx < cy || (cx == cy && x < y);
@@ -337,4 +341,74 @@ void bvh_free(BvhBuildResult* r) {
     std::free(r->leaves);
     std::free(r->model_root);
     std::memset(r, 0, sizeof *r);
+}
+
+// ---- rt_bvh_check: build on the host (no GPU), then walk the tree and verify what the traversal relies on ----
+namespace {
+struct Checker {
+    const rt_flat_scene* sc;
+    const BvhBuildResult* r;
+    std::vector<uint8_t> seen;     // per face
+    uint64_t errors = 0;
+    uint32_t depth_seen = 0;
+    // returns the exact box of the vertices below `ref`
+    Box walk(uint32_t ref, const rt_model& md, uint32_t depth) {
+        Box bx; bx.reset();
+        if (ref & RT_LEAF_BIT) {
+            const uint32_t blk = ref & RT_LEAF_START_MASK, cnt = ((ref >> 27) & 15u) + 1u;
+            if (blk >= r->n_leaves || cnt > RT_MAX_LEAF_TRIS) { ++errors; return bx; }
+            const LeafBlock& lb = r->leaves[blk];
+            for (uint32_t j = 0; j < cnt; ++j) {
+                const uint32_t f = lb.a[j].face;
+                if (f < md.first_face || f >= md.first_face + md.num_faces) { ++errors; continue; }
+                if (seen[f]++) ++errors;                       // a face in two leaves
+                const float* a = sc->v0 + 3 * size_t(f);
+                const float* b = sc->v1 + 3 * size_t(f);
+                const float* c = sc->v2 + 3 * size_t(f);
+                for (int k = 0; k < 3; ++k)                    // the arithmetic Triangle::intersect would redo
+                    if (lb.a[j].v0[k] != a[k] || lb.b[j].e1[k] != b[k] - a[k] || lb.c[j].e2[k] != c[k] - a[k]) { ++errors; break; }
+                bx.grow(a); bx.grow(b); bx.grow(c);
+            }
+            return bx;
+        }
+        if (ref >= r->n_nodes) { ++errors; return bx; }
+        depth_seen = std::max(depth_seen, depth + 1);
+        const Bvh4Node& n = r->nodes[ref];
+        bool gap = false;
+        for (int i = 0; i < 4; ++i) {
+            if (n.a[i].ref == RT_NO_CHILD) { gap = true; continue; }
+            if (gap) ++errors;                                 // children are packed to the front
+            const Box cb = walk(n.a[i].ref, md, depth + 1);
+            for (int k = 0; k < 3; ++k)
+                if (!(n.a[i].lo[k] <= cb.lo[k] && n.b[i].hi[k] >= cb.hi[k])) { ++errors; break; }
+            bx.grow(cb);
+        }
+        return bx;
+    }
+};
+}  // namespace
+
+extern "C" int rt_bvh_check(const rt_flat_scene* sc, rt_bvh_check_result* out) {
+    if (!sc || !out) return RT_ERR_INVALID;
+    std::memset(out, 0, sizeof *out);
+    BvhBuildResult r;
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = bvh_build(sc, &r);
+    out->build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (rc != 0) return RT_ERR_INVALID;
+    Checker C{sc, &r, std::vector<uint8_t>(sc->n_faces, 0)};
+    for (uint32_t m = 0; m < sc->n_models; ++m) {
+        const rt_model& md = sc->models[m];
+        if (md.num_faces == 0) { if (r.model_root[m] != RT_NO_CHILD) ++C.errors; continue; }
+        C.walk(r.model_root[m], md, 0);
+        for (uint32_t f = md.first_face; f < md.first_face + md.num_faces; ++f) if (C.seen[f] != 1) ++C.errors;
+    }
+    if (C.depth_seen != r.max_depth) ++C.errors;
+    if (r.max_stack > RT_QSTACK) ++C.errors;
+    out->n_nodes = r.n_nodes; out->n_leaves = r.n_leaves; out->n_faces = sc->n_faces;
+    out->max_depth = r.max_depth; out->max_stack = r.max_stack;
+    out->errors = C.errors;
+    out->host_bytes = uint64_t(r.n_nodes) * sizeof(Bvh4Node) + uint64_t(r.n_leaves) * sizeof(LeafBlock);
+    bvh_free(&r);
+    return RT_OK;
 }

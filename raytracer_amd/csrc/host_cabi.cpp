@@ -74,6 +74,28 @@ int rt_host_model_load_ply(const char* fname, rt_host_model** out) {
     }
 }
 
+int rt_host_model_from_arrays(const float* vertices, uint32_t n_vertices, const uint32_t* indices, uint32_t n_faces,
+                              rt_host_model** out) {
+    if (!vertices || !indices || !out || n_vertices == 0) {
+        rt_set_error("rt_host_model_from_arrays: null argument or no vertices");
+        return RT_ERR_INVALID;
+    }
+    for (size_t i = 0; i < size_t(n_faces) * 3; ++i)
+        if (indices[i] >= n_vertices) { rt_set_error("rt_host_model_from_arrays: face index out of range"); return RT_ERR_INVALID; }
+    try {
+        std::vector<Vec3f> V;
+        V.reserve(n_vertices);
+        for (uint32_t i = 0; i < n_vertices; ++i) V.push_back(v3(vertices + 3 * size_t(i)));
+        const std::vector<unsigned int> idx(indices, indices + size_t(n_faces) * 3);
+        std::unique_ptr<Model> m(Model::from_indexed(V, idx, Material(), true));
+        *out = new rt_host_model{std::move(m)};
+        return RT_OK;
+    } catch (const std::exception& e) {
+        rt_set_error("rt_host_model_from_arrays: %s", e.what());
+        return RT_ERR_INVALID;
+    }
+}
+
 int rt_host_model_transform(rt_host_model* h, const float* rot, double scale, const float* tr) {
     if (!h || !rot || !tr) { rt_set_error("rt_host_model_transform: null argument"); return RT_ERR_INVALID; }
     *h->m *= Mat3d::rotation(v3(rot));

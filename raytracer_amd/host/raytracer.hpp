@@ -338,6 +338,9 @@ struct Model : Primitive {              // ref src/primitives.h:121-159
 
     // ASCII PLY -> centred vertices -> unweighted smooth normals -> faces (ref src/primitives.cpp:238-362).
     static Model* load_ply(const std::string& fname, const Material& material, bool calcNormal = false);
+    // The part of load_ply after the text is parsed (ref :287-362): re-centre, normals, faces. `vertices` is consumed.
+    static Model* from_indexed(std::vector<Vec3f>& vertices, const std::vector<unsigned int>& idx,
+                               const Material& material, bool calcNormal);
 
     void flatten(FlatSceneBuilder& fb) const override {
         rt_model m; m.first_face = uint32_t(fb.v0.size() / 3); m.num_faces = uint32_t(faces.size());
@@ -367,7 +370,7 @@ inline Model* Model::load_ply(const std::string& fname, const Material& material
             if (key == "vertex") nvertices = val; else if (key == "face") nfaces = val;
         }
     }
-    std::vector<Vec3f> vertices, normals;
+    std::vector<Vec3f> vertices;
     vertices.reserve(nvertices);
     for (unsigned i = 0; i < nvertices; ++i) {      // first three numbers of each line (ref :279-285)
         std::getline(ifs, line);
@@ -375,12 +378,6 @@ inline Model* Model::load_ply(const std::string& fname, const Material& material
         Float x = 0, y = 0, z = 0;
         ss >> x >> y >> z;
         vertices.emplace_back(x, y, z);
-    }
-    {   // always re-centre on the vertex mean (ref :287-307)
-        Vec3f center(0, 0, 0);
-        for (const auto& v : vertices) center += v;
-        center /= Float(nvertices);
-        for (auto& v : vertices) v -= center;
     }
     std::vector<unsigned int> idx;
     idx.reserve(size_t(nfaces) * 3);
@@ -392,6 +389,19 @@ inline Model* Model::load_ply(const std::string& fname, const Material& material
         if (num != 3) throw std::runtime_error("Only triangles are supported");
         if (a >= nvertices || b >= nvertices || c >= nvertices) throw std::runtime_error("Face index out of range");
         idx.push_back(a); idx.push_back(b); idx.push_back(c);
+    }
+    return from_indexed(vertices, idx, material, calcNormal);
+}
+
+inline Model* Model::from_indexed(std::vector<Vec3f>& vertices, const std::vector<unsigned int>& idx,
+                                  const Material& material, bool calcNormal) {
+    const unsigned nvertices = unsigned(vertices.size()), nfaces = unsigned(idx.size() / 3);
+    std::vector<Vec3f> normals;
+    {   // always re-centre on the vertex mean (ref :287-307; the file's faces come after, so the order is free)
+        Vec3f center(0, 0, 0);
+        for (const auto& v : vertices) center += v;
+        center /= Float(nvertices);
+        for (auto& v : vertices) v -= center;
     }
     if (calcNormal) {                               // per-vertex sum of unit face normals, in face order (ref :322-345)
         normals.assign(vertices.size(), Vec3f(0, 0, 0));

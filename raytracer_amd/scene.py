@@ -27,6 +27,8 @@ def host_lib():
         lib.rt_host_mat3_rotation.argtypes = [C.c_float, C.c_float, C.c_float, FP]
         lib.rt_host_bbvol.argtypes = [FP, FP, FP, C.c_uint32, FP]
         lib.rt_host_model_load_ply.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        lib.rt_host_model_from_arrays.argtypes = [FP, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32,
+                                                  C.POINTER(C.c_void_p)]
         lib.rt_host_model_transform.argtypes = [C.c_void_p, FP, C.c_double, FP]
         lib.rt_host_model_num_faces.argtypes = [C.c_void_p]
         lib.rt_host_model_num_faces.restype = C.c_uint32
@@ -140,6 +142,21 @@ class Mesh:
         lib = host_lib()
         h = C.c_void_p()
         cabi.check(lib, lib.rt_host_model_load_ply(str(path).encode(), C.byref(h)))
+        return Mesh._finish(lib, h, rotation, scale, translation, transform)
+
+    @staticmethod
+    def from_arrays(V, F, rotation=(0, 0, 0), scale=1.0, translation=(0, 0, 0), transform=True):
+        """The same as writing V, F to an ASCII .ply and load_ply() (rt_host_model_from_arrays), without the text."""
+        lib = host_lib()
+        V = np.ascontiguousarray(V, dtype=np.float32).reshape(-1, 3)
+        F = np.ascontiguousarray(F, dtype=np.uint32).reshape(-1, 3)
+        h = C.c_void_p()
+        cabi.check(lib, lib.rt_host_model_from_arrays(fptr(V), V.shape[0], F.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                      F.shape[0], C.byref(h)))
+        return Mesh._finish(lib, h, rotation, scale, translation, transform)
+
+    @staticmethod
+    def _finish(lib, h, rotation, scale, translation, transform):
         try:
             if transform:
                 cabi.check(lib, lib.rt_host_model_transform(h, fptr(_f3(rotation)), float(scale),
@@ -326,6 +343,14 @@ class FlatScene:
         fs.n_faces = self.num_faces
         self._c = fs
         return fs
+
+
+def bvh_check(flat):
+    """rt_bvh_check: build the scene's BVHs on the host (no GPU) and verify them; returns the result struct."""
+    lib = cabi.load()
+    out = cabi.rt_bvh_check_result()
+    cabi.check(lib, lib.rt_bvh_check(C.byref(flat.c_struct()), C.byref(out)))
+    return out
 
 
 class DeviceScene:

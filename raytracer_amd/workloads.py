@@ -108,6 +108,32 @@ def scene_bunny(n_subdiv=59, shadows_only=False, spheres=True, third="glass"):
     return fs
 
 
+FIELD_TILT = 0.5      # radians about x: the far end of the field rises towards the camera's upper half
+
+
+def scene_field(n_blobs=2000, n_subdiv=16, seed=3):
+    """BASELINE config 5: ONE mesh of n_blobs displaced geodesic blobs on a square grid
+    (2000 x 20*16*16 = 10.24 M triangles) resting on a floor plane, a wall behind, under scene.yaml's two lights.
+    Scale 2 keeps every edge above 0.01 (the absolute |det| < 1e-6 test of Triangle::intersect, primitives.cpp:63).
+    The camera is the reference's (origin, looking down -z); field and floor are tilted by FIELD_TILT about x and
+    centred at (0,-3,-20), so the field covers the lower two thirds of the frame out to the wall at z = -40."""
+    import ctypes as C
+    from .scene import fptr, host_lib
+    fs = FlatScene()
+    mats = yaml_materials()
+    V, F = meshgen.blob_field(n_blobs, n_subdiv, seed=seed)
+    centre = np.array([0.0, -3.0, -20.0])
+    fs.add_mesh(Mesh.from_arrays(V, F, rotation=(FIELD_TILT, 0.0, 0.0), scale=2.0, translation=tuple(centre)),
+                mats["porcelan"])
+    R = np.zeros(9, np.float32)
+    assert host_lib().rt_host_mat3_rotation(C.c_float(FIELD_TILT), C.c_float(0.0), C.c_float(0.0), fptr(R)) == 0
+    n = R.reshape(3, 3).astype(np.float64) @ np.array([0.0, 1.0, 0.0])      # the field's up after Model *= rotation
+    fs.add_plane(tuple(n), float(-(n @ centre) + 0.3), mats["m1"])          # 0.3 below the blobs' centres
+    fs.add_plane((0.0, 0.0, 1.0), 40.0, mats["green"])
+    add_yaml_lights(fs)
+    return fs
+
+
 def aa_grid(n):
     """n x n stratified grid minus (0,0) (the corner ray is always cast): n*n samples per pixel."""
     pts = [((i % n) / n, (i // n) / n) for i in range(1, n * n)]
@@ -127,6 +153,10 @@ WORKLOADS = {
     "bunny_1080p": (lambda: scene_bunny(59), 1920, 1080, (), 10),
     # BASELINE config 4
     "c4_bunny_glass_4k_16spp": (lambda: scene_bunny(59, third="glass2"), 3840, 2160, aa_grid(4), 8),
+    # BASELINE config 5 (one GPU renders its 1/n_parts of the tiles; the whole frame on one GPU is the N=1 case)
+    "c5_field_10m_8k_64spp": (lambda: scene_field(), 7680, 4320, aa_grid(8), 10),
+    # the same scene at a size the tests and a quick look can afford
+    "c5_field_small_720p": (lambda: scene_field(64, 8), 1280, 720, (), 10),
 }
 
 

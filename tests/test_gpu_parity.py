@@ -96,7 +96,7 @@ def test_trace_colours(oracle_mod, third, depth):
     assert same >= 0.999
 
 
-@pytest.mark.parametrize("case", ["analytic_1spp", "analytic_9spp", "glass2", "mesh", "mesh_glass2_depth8", "mesh_rect"])
+@pytest.mark.parametrize("case", ["analytic_1spp", "analytic_9spp", "glass2", "mesh", "mesh_glass2_depth8", "mesh_rect", "field"])
 def test_frame_parity(oracle_mod, case):
     O = oracle_mod
     W, H = (800, 600) if case.startswith("analytic") or case == "glass2" else (320, 240)
@@ -113,6 +113,8 @@ def test_frame_parity(oracle_mod, case):
         fs = wl.scene_bunny(10)
     elif case == "mesh_glass2_depth8":
         fs, p = wl.scene_bunny(10, third="glass2"), Params(max_depth=8, aa=wl.aa_grid(2))
+    elif case == "field":      # BASELINE config 5's scene with 36 blobs of 320 faces
+        fs, p = wl.scene_field(36, 4), Params(aa=wl.aa_grid(2))
     else:
         fs, rect = wl.scene_bunny(10), (37, 21, 201, 107)
     dev = DeviceScene(fs)
