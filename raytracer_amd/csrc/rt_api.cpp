@@ -42,14 +42,13 @@ void rt_set_error(const char* fmt, ...) {
 // scene object
 // ---------------------------------------------------------------------------------------------------------
 struct PassCounters {                 // one per pass, zeroed by one memset per frame
-    uint32_t level[RT_MAX_LEVELS + 4];   // entries appended per level (index 0 unused)
+    ShardCounters sc[RT_SHARDS];         // per shard: entries appended / queued per level
     uint32_t cancel[RT_MAX_LEVELS + 4];  // per level: children of parents that took trace()'s `return red` exit
-    uint32_t qe[RT_MAX_LEVELS + 4];      // per level: rays k_extend_wide queued for k_extend_quad
-    uint32_t qs[RT_MAX_LEVELS + 4];      // per level: hits k_shade_wide queued for k_shade_quad
     uint32_t overflow;
     uint32_t pad[3];
     unsigned long long shadow[RT_STAT_SHARDS];
     unsigned long long work[RT_WORK_SHARDS][RT_N_KINDS][12];   // per shard: RT_K_* kernels
+    uint32_t appended(int lv) const { uint32_t n = 0; for (uint32_t k = 0; k < RT_SHARDS; ++k) n += sc[k].level[lv]; return n; }
 };
 
 #define RT_MAX_PASSES 1024
@@ -72,7 +71,7 @@ struct rt_scene {
     uint64_t scene_bytes = 0;
     bool has_bounce = false;           // some object's material is reflective or refractive
     // workspace
-    uint32_t pool_cap = 0, ws_n0 = 0;
+    uint32_t pool_cap = 0, sub_cap = 0, ws_n0 = 0;
     float4* node_a = nullptr;
     uint4* node_b = nullptr;
     float4* rays = nullptr;
@@ -87,7 +86,7 @@ struct rt_scene {
     struct CachedGraph { GraphKey key; hipGraphExec_t exec; hipStream_t last_stream; };
     std::vector<CachedGraph> graphs;     // most recently used last; at most RT_MAX_GRAPHS
     bool graph_ok = true;
-    uint32_t* h_hint = nullptr;          // pinned: level sizes of the most recent pass (async copy, read without a sync:
+    ShardCounters* h_hint = nullptr;     // pinned: level sizes of the most recent pass (async copy, read without a sync:
                                          // only a scheduling hint, results never depend on it)
     PassCounters* d_counters = nullptr;
     PassCounters* h_counters = nullptr;   // pinned
@@ -231,7 +230,7 @@ extern "C" int rt_scene_create(const rt_flat_scene* sc, int device, rt_scene** o
 
     if (hipMalloc(reinterpret_cast<void**>(&s->d_counters), sizeof(PassCounters) * RT_MAX_PASSES) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&s->h_counters), sizeof(PassCounters) * RT_MAX_PASSES) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void**>(&s->h_hint), sizeof(uint32_t) * (RT_MAX_LEVELS + 4)) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&s->h_hint), sizeof(ShardCounters) * RT_SHARDS) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&s->d_fp), sizeof(FrameParams)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&s->d_aa), sizeof(float) * 2 * (RT_MAX_AA_POINTS + 1)) != hipSuccess ||
         hipEventCreate(&s->ev_begin) != hipSuccess || hipEventCreate(&s->ev_end) != hipSuccess) {
@@ -239,7 +238,8 @@ extern "C" int rt_scene_create(const rt_flat_scene* sc, int device, rt_scene** o
         free_scene(s);
         return RT_ERR_DEVICE;
     }
-    for (int i = 0; i < RT_MAX_LEVELS + 4; ++i) s->h_hint[i] = 0xFFFFFFFFu;   // unknown: assume large levels
+    std::memset(s->h_hint, 0, sizeof(ShardCounters) * RT_SHARDS);
+    for (int i = 0; i < RT_MAX_LEVELS + 4; ++i) s->h_hint[0].level[i] = 0xFFFFFFFFu;   // unknown: assume large levels
     *out = s;
     return RT_OK;
 }
@@ -290,7 +290,7 @@ static int ensure_workspace(rt_scene* s, uint32_t n0) {
     if (n0 <= s->ws_n0) return RT_OK;
     hipFree(s->node_a); hipFree(s->node_b); hipFree(s->rays); hipFree(s->hit_n); hipFree(s->hit_p); hipFree(s->queue_e); hipFree(s->queue_s);
     s->node_a = nullptr; s->node_b = nullptr; s->rays = nullptr; s->hit_n = nullptr; s->hit_p = nullptr;
-    s->queue_e = nullptr; s->queue_s = nullptr; s->ws_n0 = 0; s->pool_cap = 0;
+    s->queue_e = nullptr; s->queue_s = nullptr; s->ws_n0 = 0; s->pool_cap = 0; s->sub_cap = 0;
     const uint64_t cap = uint64_t(n0) * (s->has_bounce ? RT_POOL_FACTOR : 1u);
     if (cap > 0xFFFFFFF0ull) { rt_set_error("pass too large"); return RT_ERR_LIMIT; }
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->node_a), cap * sizeof(float4)));
@@ -304,6 +304,7 @@ static int ensure_workspace(rt_scene* s, uint32_t n0) {
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->rays), std::max<uint64_t>(cap - n0, 1) * 2 * sizeof(float4)));
     s->ws_n0 = n0;
     s->pool_cap = uint32_t(cap);
+    s->sub_cap = uint32_t((cap - n0) / RT_SHARDS);
     return RT_OK;
 }
 
@@ -335,16 +336,34 @@ struct FrameJob {
     bool timed;              // per-launch events, everything on one stream
     uint32_t n_timed;
     std::vector<uint8_t> timed_kind;   // RT_K_*
+    float ms_by[RT_N_KINDS];           // drained event pairs, summed per kind
+    uint32_t launches_by[RT_N_KINDS];
     uint32_t n_pass_used;
     uint32_t large_mask;     // bit k: level k runs as per-lane kernel + queue (expect_large at the start of the frame)
 };
+
+// Waits for the stream and adds the recorded event pairs to the job's per-kind sums; the events are then reused.
+static int drain_timed(FrameJob& J, hipStream_t st) {
+    if (!J.n_timed) return RT_OK;
+    HIP_TRY(hipStreamSynchronize(st));
+    for (uint32_t i = 0; i < J.n_timed; ++i) {
+        float t = 0;
+        HIP_TRY(hipEventElapsedTime(&t, J.s->ev_pool[2 * i], J.s->ev_pool[2 * i + 1]));
+        J.ms_by[J.timed_kind[i]] += t;
+        J.launches_by[J.timed_kind[i]] += 1;
+    }
+    J.n_timed = 0;
+    J.timed_kind.clear();
+    return RT_OK;
+}
 
 // One kernel launch, bracketed by events when the frame is timed.
 template <typename F>
 static int timed_launch(FrameJob& J, hipStream_t st, uint8_t kind, F&& launch) {
     rt_scene* s = J.s;
     hipEvent_t e1 = nullptr;
-    if (J.timed && J.n_timed < RT_MAX_TIMED) {
+    if (J.timed && J.n_timed >= RT_MAX_TIMED) { const int rc = drain_timed(J, st); if (rc != RT_OK) return rc; }
+    if (J.timed) {
         while (s->ev_pool.size() < size_t(2 * (J.n_timed + 1))) {
             hipEvent_t e;
             HIP_TRY(hipEventCreate(&e));
@@ -364,8 +383,11 @@ static int timed_launch(FrameJob& J, hipStream_t st, uint8_t kind, F&& launch) {
 // pass of this scene (h_hint); unknown = large.
 static bool expect_large(const rt_scene* s, int lo, int hi) {
     if (lo == 0) return true;
-    for (int l = lo; l <= hi; ++l)
-        if (s->h_hint[l] > 16u * RT_LEVEL_GRID) return true;
+    for (int l = lo; l <= hi; ++l) {
+        uint64_t n = 0;
+        for (uint32_t k = 0; k < RT_SHARDS; ++k) n += s->h_hint[k].level[l];
+        if (n > 16u * RT_LEVEL_GRID) return true;
+    }
     return false;
 }
 
@@ -399,10 +421,8 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
         LevelArgs A = J.base;
         A.n0 = cnt * spp;
         A.sample0 = (px0 + done) * spp;
-        A.counters = pc->level;
+        A.sc = pc->sc;
         A.cancelled = pc->cancel;
-        A.qcount_e = pc->qe;
-        A.qcount_s = pc->qs;
         A.overflow = &pc->overflow;
         A.shadow_count = pc->shadow;
         A.work = &pc->work[0][0][0];
@@ -416,7 +436,6 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
         int last_wait[3] = {-1, -1, -1};
         // (a "lean" schedule for small passes - one shade stream, one shade launch for all small levels, deep levels folded
         // by one workgroup, 30 API calls instead of 50 - was measured SLOWER: 0.27 vs 0.24 ms for an eighth of the frame)
-        const bool lean = false;
         // diagnostics: RT_WAVE_LOG=<level>:<file> dumps per-workgroup timing of that level's quad extend kernel (COUNT builds)
         uint4* wave_log = nullptr;
         int log_level = -1;
@@ -431,19 +450,25 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
         }
         // shade launch `form` over levels lo..hi on the level's shade stream, after event `after` of stream A
         auto shade = [&](int form, int lo, int hi, int after) -> int {
-            const int which = lean ? 0 : (form == RT_FORM_QUAD_FRESH ? 2 : (lo & 1));
+            const int which = form == RT_FORM_QUAD_FRESH ? 2 : (lo & 1);
             hipStream_t sb = overlap ? s->shade_stream[which] : sa;
             if (overlap) {
                 if (last_wait[which] != after) HIP_TRY(hipStreamWaitEvent(sb, s->ev_sync[after], 0));
                 last_wait[which] = after;
                 used_shade[which] = true;
             }
-            LevelArgs B = A;
-            B.level = lo; B.level_hi = hi;
-            const uint32_t g = form == RT_FORM_WIDE ? (hi == 0 ? grid0 : RT_LEVEL_GRID)
-                               : (hi == 0 ? grid0q : (form == RT_FORM_QUAD_FRESH ? RT_LEVEL_GRID : 4u * RT_LEVEL_GRID));
-            return timed_launch(J, sb, form == RT_FORM_WIDE ? RT_K_SHADE_WIDE : form == RT_FORM_QUAD_PARKED ? RT_K_SHADE_PARKED : RT_K_SHADE_QUAD,
-                                [&] { launch_shade(form, s->count_work, s->d, B, g, sb); });
+            // level 0 lies in sample order, the deeper levels in the sub-pools: a range that starts at level 0 is two launches
+            for (int part = (lo == 0 && hi > 0) ? 0 : 1; part < 2; ++part) {
+                LevelArgs B = A;
+                B.level = part == 0 ? 0 : (lo == 0 && hi > 0 ? 1 : lo);
+                B.level_hi = part == 0 ? 0 : hi;
+                const uint32_t g = form == RT_FORM_WIDE ? (B.level_hi == 0 ? grid0 : RT_LEVEL_GRID)
+                                   : (B.level_hi == 0 ? grid0q : (form == RT_FORM_QUAD_FRESH ? RT_LEVEL_GRID : 4u * RT_LEVEL_GRID));
+                const int rc2 = timed_launch(J, sb, form == RT_FORM_WIDE ? RT_K_SHADE_WIDE : form == RT_FORM_QUAD_PARKED ? RT_K_SHADE_PARKED : RT_K_SHADE_QUAD,
+                                             [&] { launch_shade(form, s->count_work, s->d, B, g, sb); });
+                if (rc2 != RT_OK) return rc2;
+            }
+            return RT_OK;
         };
         int small_lo = -1;      // first level of the run of small levels not shaded yet
         for (int lv = 0; lv <= levels; ++lv) {
@@ -474,7 +499,7 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
                 B.wave_log = (lv == log_level) ? wave_log : nullptr;
                 if ((rc = timed_launch(J, sa, RT_K_EXTEND_QUAD, [&] { launch_extend(src, RT_FORM_QUAD_FRESH, s->count_work, s->d, B, RT_LEVEL_GRID, sa); })) != RT_OK) return rc;
                 if (small_lo < 0) small_lo = lv;
-                if (!lean && lv - small_lo + 1 >= 3 && lv < levels) {     // shade a run of three small levels while the deeper ones are traced
+                if (lv - small_lo + 1 >= 3 && lv < levels) {     // shade a run of three small levels while the deeper ones are traced
                     if (overlap) HIP_TRY(hipEventRecord(s->ev_sync[2 * lv + 1], sa));
                     if ((rc = shade(RT_FORM_QUAD_FRESH, small_lo, lv, 2 * lv + 1)) != RT_OK) return rc;
                     small_lo = -1;
@@ -498,13 +523,7 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
                 HIP_TRY(hipEventRecord(s->ev_sync[2 * RT_MAX_LEVELS + 1 + k], s->shade_stream[k]));
                 HIP_TRY(hipStreamWaitEvent(sa, s->ev_sync[2 * RT_MAX_LEVELS + 1 + k], 0));
             }
-        int fold_hi = levels - 1;
-        if (lean && levels - 1 >= 3) {        // levels 2.. in one single-workgroup launch
-            A.level = 2; A.level_hi = levels - 1;
-            launch_fold_tail(s->d, A, sa);
-            fold_hi = 1;
-        }
-        for (int lv = fold_hi; lv >= 1; --lv) {
+        for (int lv = levels - 1; lv >= 1; --lv) {
             A.level = lv; A.level_hi = lv;
             launch_fold(s->d, A, 1024, sa);
         }
@@ -512,7 +531,7 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
         launch_resolve(s->d, A, J.d_out, sa);
         HIP_TRY(hipGetLastError());
         // level sizes of this pass -> scheduling hint of the next one (no sync; see h_hint)
-        HIP_TRY(hipMemcpyAsync(s->h_hint, pc->level, sizeof(uint32_t) * (RT_MAX_LEVELS + 4), hipMemcpyDeviceToHost, sa));
+        HIP_TRY(hipMemcpyAsync(s->h_hint, pc->sc, sizeof(ShardCounters) * RT_SHARDS, hipMemcpyDeviceToHost, sa));
         recs.push_back({px0 + done, cnt, slot});
     }
     return RT_OK;
@@ -536,7 +555,9 @@ static int render_frame(rt_scene* s, const rt_camera* cam, const rt_params* prm,
     std::memset(&B, 0, sizeof B);
     B.max_depth = prm->max_depth;
     B.spp = spp;
-    B.pool_cap = s->pool_cap;
+    B.sub_cap = s->sub_cap;
+    B.chunk_log2 = RT_SHARD_CHUNK_LOG2;
+    if (const char* e = std::getenv("RT_CHUNK_LOG2")) B.chunk_log2 = std::min<uint32_t>(uint32_t(std::atoi(e)), RT_SHARD_CHUNK_LOG2_MAX);   // experiments
     if (const char* dbg = std::getenv("RT_DEBUG_SKIP")) { B.debug = uint32_t(std::atoi(dbg)); s->d.debug = B.debug; }   // timing experiments only
     B.rays = s->rays; B.node_a = s->node_a; B.node_b = s->node_b; B.hit_n = s->hit_n; B.hit_p = s->hit_p; B.queue_e = s->queue_e; B.queue_s = s->queue_s;
     B.aa = s->d_aa;
@@ -651,7 +672,7 @@ static int render_frame(rt_scene* s, const rt_camera* cam, const rt_params* prm,
             const PassCounters& pc = s->h_counters[r.slot];
             // level 0: every valid sample is one trace() call; deeper levels: appended entries
             for (int k = 0; k < RT_STAT_SHARDS; ++k) stats->shadow_rays += pc.shadow[k];
-            for (int lv = 1; lv < RT_MAX_LEVELS; ++lv) stats->level_rays[lv] += pc.level[lv] - pc.cancel[lv];
+            for (int lv = 1; lv < RT_MAX_LEVELS; ++lv) stats->level_rays[lv] += pc.appended(lv) - pc.cancel[lv];
             for (int sh = 0; sh < RT_WORK_SHARDS; ++sh) for (int k = 0; k < RT_N_KINDS; ++k) add_work(w[k], pc.work[sh][k]);
         }
         for (int k = 0; k < RT_N_KINDS; ++k) s->last_work[k] = w[k];
@@ -660,11 +681,10 @@ static int render_frame(rt_scene* s, const rt_camera* cam, const rt_params* prm,
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, s->ev_begin, s->ev_end));
         stats->kernel_ms = ms;
-        for (uint32_t i = 0; i < J.n_timed; ++i) {
-            float t = 0;
-            HIP_TRY(hipEventElapsedTime(&t, s->ev_pool[2 * i], s->ev_pool[2 * i + 1]));
-            stats->kernel_ms_by[J.timed_kind[i]] += t;
-            stats->kernel_launches_by[J.timed_kind[i]] += 1;
+        if ((rc = drain_timed(J, st)) != RT_OK) return rc;
+        for (int k = 0; k < RT_N_KINDS; ++k) {
+            stats->kernel_ms_by[k] += J.ms_by[k];
+            stats->kernel_launches_by[k] += J.launches_by[k];
         }
     }
     return RT_OK;
@@ -856,16 +876,15 @@ static int trace_chunk(rt_scene* s, const rt_params* prm, const float* d_rays, u
     LevelArgs A;
     std::memset(&A, 0, sizeof A);
     A.n0 = n; A.max_depth = prm->max_depth; A.spp = 1;
-    A.counters = s->d_counters->level; A.cancelled = s->d_counters->cancel; A.overflow = &s->d_counters->overflow;
-    A.qcount_e = s->d_counters->qe; A.qcount_s = s->d_counters->qs;
+    A.sc = s->d_counters->sc; A.cancelled = s->d_counters->cancel; A.overflow = &s->d_counters->overflow;
     A.shadow_count = s->d_counters->shadow;
     A.work = &s->d_counters->work[0][0][0];
     A.node_a = s->node_a; A.node_b = s->node_b; A.hit_n = s->hit_n; A.hit_p = s->hit_p; A.user_rays = d_rays;
     A.queue_e = s->queue_e; A.queue_s = s->queue_s;
-    // pool entry i >= n0 keeps its ray at rays[2*(i-n0)]; the ray array holds pool_cap - ws_n0 entries, so with
-    // n0 = n <= ws_n0 the usable pool shrinks accordingly
+    // pool entry i >= n0 keeps its ray at rays[2*(i-n0)]: the sub-pools are the same size whatever n0 <= ws_n0 is
     A.rays = s->rays;
-    A.pool_cap = s->pool_cap - (s->ws_n0 - n);
+    A.sub_cap = s->sub_cap;
+    A.chunk_log2 = RT_SHARD_CHUNK_LOG2;
     FrameParams fp;
     std::memset(&fp, 0, sizeof fp);
     std::memcpy(fp.background, prm->background, sizeof fp.background);
@@ -880,10 +899,12 @@ static int trace_chunk(rt_scene* s, const rt_params* prm, const float* d_rays, u
         launch_extend(lv == 0 ? 2 : 1, RT_FORM_WIDE, s->count_work, s->d, A, lv == 0 ? (n + RT_BLOCK - 1) / RT_BLOCK : RT_LEVEL_GRID, st);
         if (meshes) launch_extend(lv == 0 ? 2 : 1, RT_FORM_QUAD_RESUME, s->count_work, s->d, A, lv == 0 ? gq : 4u * RT_LEVEL_GRID, st);
     }
-    A.level = 0; A.level_hi = levels;
-    launch_shade(RT_FORM_WIDE, s->count_work, s->d, A, std::max<uint32_t>((n + RT_BLOCK - 1) / RT_BLOCK, levels ? RT_LEVEL_GRID : 1u), st);
+    for (int part = 0; part < (levels ? 2 : 1); ++part) {      // level 0 (sample order), then levels 1.. (the sub-pools)
+        A.level = part; A.level_hi = part ? levels : 0;
+        launch_shade(RT_FORM_WIDE, s->count_work, s->d, A, part ? RT_LEVEL_GRID : (n + RT_BLOCK - 1) / RT_BLOCK, st);
+        if (meshes) launch_shade(RT_FORM_QUAD_RESUME, s->count_work, s->d, A, 4u * RT_LEVEL_GRID, st);
+    }
     if (meshes) {
-        launch_shade(RT_FORM_QUAD_RESUME, s->count_work, s->d, A, 4u * RT_LEVEL_GRID, st);
         for (int lv = 0; lv <= levels; ++lv) {      // the hits of the rays each level parked
             A.level = lv; A.level_hi = lv;
             launch_shade(RT_FORM_QUAD_PARKED, s->count_work, s->d, A, lv == 0 ? gq : 4u * RT_LEVEL_GRID, st);
@@ -899,7 +920,7 @@ static int trace_chunk(rt_scene* s, const rt_params* prm, const float* d_rays, u
     *overflow = pc.overflow != 0;
     if (!*overflow && stats) {
         stats->level_rays[0] += n;
-        for (int lv = 1; lv < RT_MAX_LEVELS; ++lv) stats->level_rays[lv] += pc.level[lv] - pc.cancel[lv];
+        for (int lv = 1; lv < RT_MAX_LEVELS; ++lv) stats->level_rays[lv] += pc.appended(lv) - pc.cancel[lv];
         for (int k = 0; k < RT_STAT_SHARDS; ++k) stats->shadow_rays += pc.shadow[k];
         stats->passes += 1;
         for (int sh = 0; sh < RT_WORK_SHARDS; ++sh) for (int k = 0; k < RT_N_KINDS; ++k) add_work(s->last_work[k], pc.work[sh][k]);

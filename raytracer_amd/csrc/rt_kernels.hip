@@ -541,28 +541,58 @@ __device__ __forceinline__ bool map_pixel(const PixelMap& pm, uint64_t q, uint32
 //   SRC 0: level 0, rays generated from the camera     SRC 1: level >= 1, rays read from the pool
 //   SRC 2: level 0, rays supplied by the caller (rt_trace)
 // ---------------------------------------------------------------------------------------------------------
+#define RT_RUN_LOG2 3u    // see group_of: runs of 8 groups (measured: 1, 2, 4 and 16 within 3 %; 64+ and one strip per CU 5-20 % slower). Experiments: RT_DEBUG_SKIP = run_log2 << 8
 #define NODE_HIT 4u      // has a hit record: k_shade computes its colour
-#define NODE_PARKED 8u   // the ray went through the extend queue: its hit is shaded from that queue (k_shade_quad<2>),
-                         // not by k_shade_wide, which may run before the queue has been worked off
+#define NODE_PARKED 8u   // the ray was suspended by k_extend_wide and finished by k_extend_quad: its hit is shaded by
+                         // k_shade_quad<2>, not by k_shade_wide, which may run before k_extend_quad is done
+#define NODE_SPARKED 16u // the hit's light loop was suspended by k_shade_wide (level 0: the mark k_shade_quad<1> looks for)
 
-// Pool range [begin, end) of levels lo..hi (level 0 = [0, n0), level k >= 1 behind level k-1). 64-bit sums: after an
-// overflow the counters hold the ATTEMPTED appends (flagged by the producing level).
-__device__ __forceinline__ void level_range(const LevelArgs& A, int lo, int hi, uint32_t& begin, uint32_t& end) {
-    uint64_t b = 0, e = A.n0;
-    for (int l = 1; l <= hi; ++l) {
-        if (l == lo) b = e;
-        e += A.counters[l];
-    }
-    begin = (uint32_t)(b < A.pool_cap ? b : A.pool_cap);
-    end = (uint32_t)(e < A.pool_cap ? e : A.pool_cap);
+// ---- shards (rt_launch.h): every kernel walks its items shard by shard, in groups that lie in ONE shard, so that a
+// wave's appends go to that shard's counters ----
+__device__ __forceinline__ uint32_t lane_read(uint32_t v, uint32_t lane) {      // lane: wave-uniform
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane((int)lane));
 }
 
-// Rays per wave. Level 0 and large levels fill all 64 lanes. A range with few rays (deep bounces) is spread over the
-// whole grid instead, R rays per wave: its rays are incoherent, so a wave's time is close to the SUM of its lanes'
-// paths, and fewer lanes per wave shorten the critical path at no cost in total issue slots.
-__device__ __forceinline__ uint32_t rays_per_wave(uint32_t n_items) {
-    const uint32_t per = (n_items + gridDim.x - 1) / gridDim.x;
-    return per < 1u ? 1u : (per < RT_BLOCK ? per : RT_BLOCK);
+// Lane s (mod RT_SHARDS): what sub-pool s holds of levels lo..hi (lo >= 1). lo = hi = 0 gives the empty view at the
+// start of the sub-pool (where level 1 is appended). 64-bit sums: after an overflow the counters hold the ATTEMPTED
+// appends (flagged by the producing level).
+struct ShardView { uint32_t start, cnt; };
+__device__ __forceinline__ ShardView shard_view(const LevelArgs& A, int lo, int hi) {
+    const uint32_t s = lane_id() & (RT_SHARDS - 1u);
+    const ShardCounters* c = A.sc + s;
+    uint64_t b = 0, e = 0;
+    for (int l = 1; l <= hi; ++l) {
+        if (l == lo) b = e;
+        e += c->level[l];
+    }
+    if (b > A.sub_cap) b = A.sub_cap;
+    if (e > A.sub_cap) e = A.sub_cap;
+    ShardView v;
+    v.start = A.n0 + s * A.sub_cap + (uint32_t)b;
+    v.cnt = (uint32_t)(e - b);
+    return v;
+}
+// Level 0 has no queues: a suspended entry is MARKED (NODE_PARKED / NODE_SPARKED in node_b.w) and the quad kernels pick
+// the marked entries of each 64-entry block in sample order. (Queues filled by atomics hold the entries in the order
+// the waves happened to finish; with a scene far larger than the L2 - 10 M triangles - traversing the primary rays
+// in that order took 1.6x as long as in sample order.) Group `pos` = block (pos & ~63), run (pos & 63) / R of R marked
+// entries. `mask` = the block's marks (lane l = entry block + l). Returns whether this quad has an entry.
+__device__ __forceinline__ uint32_t select_bit(unsigned long long mask, uint32_t q) {     // index of the q-th set bit
+    uint32_t lo = (uint32_t)mask, pos = 0;
+    uint32_t c = (uint32_t)__popc(lo);
+    if (q >= c) { q -= c; pos = 32; lo = (uint32_t)(mask >> 32); }
+#pragma unroll
+    for (uint32_t w = 16; w >= 1; w >>= 1) {
+        c = (uint32_t)__popc(lo & ((1u << w) - 1u));
+        if (q >= c) { q -= c; pos += w; lo >>= w; }
+    }
+    return pos;
+}
+__device__ __forceinline__ bool pick_marked(unsigned long long mask, uint32_t pos, uint32_t R, uint32_t quad, uint32_t& i) {
+    const uint32_t rank = (pos & 63u) + quad;
+    const bool have = quad < R && rank < (uint32_t)__popcll(mask);
+    i = (pos & ~63u) + (have ? select_bit(mask, rank) : 0u);
+    return have;
 }
 
 __device__ __forceinline__ void flush_work(unsigned long long* work, uint32_t kernel, const Work& wk) {
@@ -617,7 +647,7 @@ __device__ __forceinline__ bool fetch_ray(const LevelArgs& A, uint32_t begin, ui
 // the per-lane kernels, lane 0 of the quad in the quad kernels). Called with the whole wave converged.
 __device__ __forceinline__ void extend_finish(const DScene& S, const LevelArgs& A, uint32_t i, bool active, bool valid,
                                               bool writer, const Ray& ray, const HitState& h, uint32_t next_base,
-                                              uint32_t* next_count, uint32_t extra_flags) {
+                                              uint32_t next_end, uint32_t* next_count, uint32_t extra_flags) {
     uint4 rec_b = make_uint4(RT_NO_CHILD, RT_NO_CHILD, 0, 0);
     bool want_refl = false, want_refr = false;
     Ray r_refl, r_refr;
@@ -666,14 +696,14 @@ __device__ __forceinline__ void extend_finish(const DScene& S, const LevelArgs& 
         }
     }
 
-    // append child rays to the next level: one atomic per wave
+    // append child rays to the next level of the wave's shard: one atomic per wave
     want_refl = want_refl && writer;
     want_refr = want_refr && writer;
     uint32_t s1, s2;
     wave_append2(next_count, want_refl, want_refr, s1, s2);
     if (want_refl) {
         const uint64_t slot = (uint64_t)next_base + s1;
-        if (slot < A.pool_cap) {
+        if (slot < next_end) {
             A.rays[2 * (size_t)(slot - A.n0)] = make_float4(r_refl.o.x, r_refl.o.y, r_refl.o.z, 0);
             A.rays[2 * (size_t)(slot - A.n0) + 1] = make_float4(r_refl.d.x, r_refl.d.y, r_refl.d.z, 0);
             rec_b.x = (uint32_t)slot;
@@ -683,7 +713,7 @@ __device__ __forceinline__ void extend_finish(const DScene& S, const LevelArgs& 
     }
     if (want_refr) {
         const uint64_t slot = (uint64_t)next_base + s2;
-        if (slot < A.pool_cap) {
+        if (slot < next_end) {
             A.rays[2 * (size_t)(slot - A.n0)] = make_float4(r_refr.o.x, r_refr.o.y, r_refr.o.z, 0);
             A.rays[2 * (size_t)(slot - A.n0) + 1] = make_float4(r_refr.d.x, r_refr.d.y, r_refr.d.z, 0);
             rec_b.y = (uint32_t)slot;
@@ -713,46 +743,105 @@ __device__ __forceinline__ HitState fresh_hit() {
     return h;
 }
 
-// k_extend_wide: one ray per lane. Rays that never reach a mesh are finished here; the others are queued.
-template <int SRC, bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) void k_extend_wide(DScene S, LevelArgs A) {
-    uint32_t begin = 0, end = A.n0;
-    if (SRC == 1) level_range(A, A.level, A.level, begin, end);
-    const uint32_t next_base = end;               // children of this level are appended behind it
-    uint32_t* next_count = A.counters + (A.level + 1);
-    Work wk = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (COUNT) { wk.t_start = wall_clock64(); wk.c_start = clock64(); }
-
-    const uint32_t n_items = end - begin;
-    const uint32_t n_groups = (n_items + RT_BLOCK - 1) / RT_BLOCK;
-    for (uint32_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
-        const uint32_t i = begin + grp * RT_BLOCK + threadIdx.x;
-        const bool active = i < end;
-        Ray ray;
-        ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 0);
-        const bool valid = active && fetch_ray<SRC>(A, begin, i, ray);
-        HitState h = fresh_hit();
-        int susp = -1;
-        if (!(A.debug & 2u)) susp = closest_loop<false, COUNT>(S, ray, valid, 0, h, nullptr, wk);
-        const bool parked = susp >= 0;
-        const uint32_t qslot = wave_append(A.qcount_e + A.level, parked);
-        if (parked) {
-            A.node_b[i] = make_uint4(RT_NO_CHILD, RT_NO_CHILD, 0, NODE_PARKED);
-            A.queue_e[begin + qslot] = make_uint2(i, (uint32_t)susp);
-            A.hit_n[i] = make_float4(h.n.x, h.n.y, h.n.z, h.tmpdist);
-            A.hit_p[i] = make_float4(h.dist, __int_as_float(h.cur), __uint_as_float(h.mat), 0);
-        }
-        extend_finish(S, A, i, active && !parked, valid && !parked, true, ray, h, next_base, next_count, 0u);
-    }
-    if (COUNT) flush_work(A.work, 0, wk);
-}
-
 // Rays per wave of a quad kernel: 16, or fewer when the items would not fill the chip's wave slots anyway (a wave
 // lasts as long as its longest ray; with everything resident at once, thinner waves end sooner).
 __device__ __forceinline__ uint32_t quads_per_wave(uint32_t n_items) {
     const uint32_t slots = gridDim.x < 4096u ? gridDim.x : 4096u;
     const uint32_t per = (n_items + slots - 1) / slots;
     return per < 1u ? 1u : (per < 16u ? per : 16u);
+}
+
+// The groups (R items each, one wave's worth) a kernel's waves loop over.
+struct Groups {
+    uint32_t first, cnt, gend;   // lane s < RT_SHARDS: index range of shard s (pool or queue indices), inclusive group count
+    uint32_t total;              // groups in all
+    uint32_t R;                  // items per group
+    uint32_t n_dense;            // != 0: level 0 in pool order: group g = items [g*R, g*R + R) of n_dense
+    uint32_t chunk_log2;
+};
+template <bool QUAD>
+__device__ __forceinline__ Groups make_groups(uint32_t first, uint32_t cnt) {
+    Groups G;
+    const uint32_t lane = lane_id();
+    if (lane >= RT_SHARDS) cnt = 0;
+    G.first = first; G.cnt = cnt; G.n_dense = 0; G.chunk_log2 = 0;
+    G.R = QUAD ? quads_per_wave(wave_sum(cnt)) : (uint32_t)RT_BLOCK;
+    uint32_t v = (cnt + G.R - 1) / G.R;
+    for (uint32_t off = 1; off < RT_SHARDS; off <<= 1) {
+        const uint32_t t = __shfl_up(v, off);
+        if (lane >= off) v += t;
+    }
+    G.gend = v;
+    G.total = lane_read(v, RT_SHARDS - 1u);
+    return G;
+}
+template <bool QUAD>
+__device__ __forceinline__ Groups make_groups_dense(uint32_t n, uint32_t chunk_log2) {
+    Groups G;
+    G.chunk_log2 = chunk_log2;
+    G.first = G.cnt = G.gend = 0;
+    G.n_dense = n;
+    uint32_t R = RT_BLOCK;
+    if (QUAD) { R = quads_per_wave(n); R = 1u << (31 - __clz((int)R)); }     // a group must not straddle two shards
+    G.R = R;
+    G.total = (n + R - 1) / R;
+    return G;
+}
+// Workgroup -> group. Workgroups whose ids are congruent mod 256 tend to share a CU (ids go round-robin over the 8
+// XCDs, then over an XCD's CUs): they get RUNS of consecutive groups (neighbouring rays, the same part of the tree,
+// in the same 32-KB L1), and the runs go round the CUs so that a part of the frame with more work than the rest is
+// spread over all of them. run_log2 = 31: one run per CU (a strip of the frame each).
+__device__ __forceinline__ uint32_t group_of(uint32_t vb, uint32_t per_cu, uint32_t run_log2) {
+    const uint32_t cu = vb & 255u, k = vb >> 8;
+    if (run_log2 >= 31u) return cu * per_cu + k;
+    return ((((k >> run_log2) << 8) + cu) << run_log2) + (k & ((1u << run_log2) - 1u));
+}
+
+// Group grp (wave-uniform, < G.total): its shard, the index of its first item and the end of the shard's range.
+__device__ __forceinline__ void locate(const Groups& G, uint32_t grp, uint32_t& shard, uint32_t& pos, uint32_t& lim) {
+    if (G.n_dense) { pos = grp * G.R; lim = G.n_dense; shard = rt_shard_of_level0(pos, G.chunk_log2); return; }
+    shard = (uint32_t)__popcll(__ballot(lane_id() < RT_SHARDS && G.gend <= grp));
+    const uint32_t prev = shard ? lane_read(G.gend, shard - 1u) : 0u;
+    const uint32_t f = lane_read(G.first, shard);
+    pos = f + (grp - prev) * G.R;
+    lim = f + lane_read(G.cnt, shard);
+}
+
+// k_extend_wide: one ray per lane. Rays that never reach a mesh are finished here; the others are queued.
+template <int SRC, bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) void k_extend_wide(DScene S, LevelArgs A) {
+    const bool level0 = SRC != 1;
+    const ShardView v = shard_view(A, A.level, A.level);
+    const Groups G = level0 ? make_groups_dense<false>(A.n0, A.chunk_log2) : make_groups<false>(v.start, v.cnt);
+    const uint32_t next_base_l = v.start + v.cnt;     // lane s: children of shard s are appended behind its level
+    Work wk = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (COUNT) { wk.t_start = wall_clock64(); wk.c_start = clock64(); }
+
+    for (uint32_t grp = blockIdx.x; grp < G.total; grp += gridDim.x) {
+        uint32_t shard, pos, lim;
+        locate(G, grp, shard, pos, lim);
+        const uint32_t i = pos + threadIdx.x;
+        const bool active = i < lim;
+        Ray ray;
+        ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 0);
+        const bool valid = active && fetch_ray<SRC>(A, 0, i, ray);
+        HitState h = fresh_hit();
+        int susp = -1;
+        if (!(A.debug & 2u)) susp = closest_loop<false, COUNT>(S, ray, valid, 0, h, nullptr, wk);
+        const bool parked = susp >= 0;
+        ShardCounters* sc = A.sc + shard;
+        uint32_t qslot = 0;
+        if (!level0) qslot = wave_append(sc->qe + A.level, parked);
+        if (parked) {
+            A.node_b[i] = make_uint4(RT_NO_CHILD, RT_NO_CHILD, (uint32_t)susp, NODE_PARKED);   // .z: where to resume
+            if (!level0) A.queue_e[lane_read(v.start, shard) + qslot] = make_uint2(i, (uint32_t)susp);
+            A.hit_n[i] = make_float4(h.n.x, h.n.y, h.n.z, h.tmpdist);
+            A.hit_p[i] = make_float4(h.dist, __int_as_float(h.cur), __uint_as_float(h.mat), 0);
+        }
+        extend_finish(S, A, i, active && !parked, valid && !parked, true, ray, h, lane_read(next_base_l, shard),
+                      A.n0 + (shard + 1u) * A.sub_cap, sc->level + (A.level + 1), 0u);
+    }
+    if (COUNT) flush_work(A.work, 0, wk);
 }
 
 // k_extend_quad: one ray per quad. FRESH: all rays of the level from the start (levels with few rays: no per-lane
@@ -763,43 +852,58 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_quad(DScene S, LevelArgs A)
     const uint32_t quad = threadIdx.x >> 2, j = threadIdx.x & 3u;
     uint32_t* qs = lds_stack + quad;
 
-    uint32_t begin = 0, end = A.n0;
-    if (SRC == 1) level_range(A, A.level, A.level, begin, end);
-    const uint32_t next_base = end;
-    uint32_t* next_count = A.counters + (A.level + 1);
+    const bool level0 = SRC != 1;
+    const ShardView v = shard_view(A, A.level, A.level);
+    const uint32_t next_base_l = v.start + v.cnt;
+    Groups G;
+    if (FRESH) {
+        G = level0 ? make_groups_dense<true>(A.n0, A.chunk_log2) : make_groups<true>(v.start, v.cnt);
+    } else if (level0) {      // the marked entries, block by block
+        G = make_groups_dense<true>(A.n0, A.chunk_log2);
+    } else {                  // the shard's queue
+        const uint32_t q = A.sc[lane_id() & (RT_SHARDS - 1u)].qe[A.level];
+        G = make_groups<true>(v.start, q < v.cnt ? q : v.cnt);
+    }
     Work wk = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (COUNT) { wk.t_start = wall_clock64(); wk.c_start = clock64(); }
 
-    uint32_t n_items = end - begin;
-    if (!FRESH) { n_items = A.qcount_e[A.level]; n_items = n_items < end - begin ? n_items : end - begin; }
-    const uint32_t R = quads_per_wave(n_items);
-    const uint32_t n_groups = (n_items + R - 1) / R;
-    // Workgroup -> group mapping: workgroups whose ids are congruent mod 256 tend to share a CU (ids go round-robin
-    // over the 8 XCDs, then over an XCD's CUs), so they get CONSECUTIVE groups: neighbouring rays, the same part of
-    // the tree, in the same 32-KB L1.
-    const uint32_t per_cu = (n_groups + 255u) >> 8;
+    const uint32_t R = G.R;
+    // Workgroup -> group mapping: see group_of
+    const uint32_t run_log2 = (A.debug >> 8) ? ((A.debug >> 8) & 31u) : RT_RUN_LOG2;
+    const uint32_t rl = run_log2 >= 31u ? 0u : run_log2;
+    const uint32_t per_cu = ((((G.total + 255u) >> 8) + (1u << rl) - 1u) >> rl) << rl;
     for (uint32_t vb = blockIdx.x; vb < per_cu * 256u; vb += gridDim.x) {
-        const uint32_t grp = (vb & 255u) * per_cu + (vb >> 8);
-        if (grp >= n_groups) continue;
-        const uint32_t idx = grp * R + quad;
-        const bool active = quad < R && idx < n_items;
-        uint32_t i = begin + idx, k0 = 0;
+        const uint32_t grp = group_of(vb, per_cu, run_log2);
+        if (grp >= G.total) continue;
+        uint32_t shard, pos, lim;
+        locate(G, grp, shard, pos, lim);
+        bool active = quad < R && pos + quad < lim;
+        uint32_t i = pos + quad, k0 = 0;
         HitState h = fresh_hit();
-        if (!FRESH && active) {
-            const uint2 e = A.queue_e[begin + idx];
+        if (!FRESH && level0) {
+            const uint32_t il = (pos & ~63u) + lane_id();
+            const unsigned long long marks = __ballot(il < lim && (A.node_b[il].w & NODE_PARKED) != 0);
+            if ((uint32_t)__popcll(marks) <= (pos & 63u)) continue;                              // wave-uniform
+            active = pick_marked(marks, pos, R, quad, i);
+            if (active) k0 = A.node_b[i].z;
+        } else if (!FRESH && active) {
+            const uint2 e = A.queue_e[pos + quad];
             i = e.x; k0 = e.y;
+        }
+        if (!FRESH && active) {
             const float4 a = A.hit_n[i], b = A.hit_p[i];
             h.n = f4xyz(a); h.tmpdist = a.w; h.dist = b.x; h.cur = __float_as_int(b.y); h.mat = __float_as_uint(b.z);
         }
         Ray ray;
         ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 0);
-        const bool valid = active && fetch_ray<SRC>(A, begin, i, ray);
+        const bool valid = active && fetch_ray<SRC>(A, 0, i, ray);
         if (COUNT) { wk.batches++; }
         unsigned long long c0 = 0;
         if (COUNT) c0 = wall_clock64();
         if (!(A.debug & 2u)) closest_loop<true, COUNT>(S, ray, valid, k0, h, qs, wk);
         if (COUNT) wk.trav_ticks += wall_clock64() - c0;
-        extend_finish(S, A, i, active, valid, j == 0, ray, h, next_base, next_count, FRESH ? 0u : NODE_PARKED);
+        extend_finish(S, A, i, active, valid, j == 0, ray, h, lane_read(next_base_l, shard), A.n0 + (shard + 1u) * A.sub_cap,
+                      A.sc[shard].level + (A.level + 1), FRESH ? 0u : NODE_PARKED);
     }
     if (COUNT) flush_work(A.work, 2, wk);
     if (COUNT && A.wave_log && lane_id() == 0)
@@ -852,10 +956,13 @@ __device__ __forceinline__ void shade_ray(const DScene& S, const LevelArgs& A, u
     } else if (red) {
         A.node_a[i] = make_float4(1, 0, 0, 0);
         if (b.w & NODE_FOLD) {      // children were appended speculatively: ignore them, and un-count them
-            A.node_b[i].w = NODE_VALID;
-            uint32_t lo = 0, hi = 0;
-            int lv = 0;
-            for (; lv < RT_MAX_LEVELS; ++lv) { level_range(A, lv, lv, lo, hi); if (i < hi) break; }
+            A.node_b[i].w = b.w & ~NODE_FOLD;      // (the marks the level-0 quad kernels select by stay as they are)
+            int lv = 0;         // the level of entry i: walk its sub-pool
+            if (i >= A.n0) {
+                const uint32_t sh = (i - A.n0) / A.sub_cap, off = (i - A.n0) - sh * A.sub_cap;
+                uint64_t e = 0;
+                for (lv = 1; lv < RT_MAX_LEVELS; ++lv) { e += A.sc[sh].level[lv]; if (off < e) break; }
+            }
             atomicAdd(A.cancelled + lv + 1, (b.x != RT_NO_CHILD ? 1u : 0u) + (b.y != RT_NO_CHILD ? 1u : 0u));
         }
     } else if (b.w & NODE_FOLD) {
@@ -877,17 +984,18 @@ __device__ __forceinline__ void flush_shadow(const LevelArgs& A, uint32_t n_shad
 // reach a mesh are finished here; the others are queued (queue of A.level) at the point they stopped.
 template <bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK) void k_shade_wide(DScene S, LevelArgs A) {
-    uint32_t begin = 0, end = A.n0;
-    if (A.level_hi > 0) level_range(A, A.level, A.level_hi, begin, end);
+    const bool level0 = A.level == 0;                 // then level_hi == 0: level 0 is not part of a range
+    const ShardView v = shard_view(A, A.level, A.level_hi);
+    const Groups G = level0 ? make_groups_dense<false>(A.n0, A.chunk_log2) : make_groups<false>(v.start, v.cnt);
     Work wk = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (COUNT) { wk.t_start = wall_clock64(); wk.c_start = clock64(); }
     uint32_t n_shadow = 0;
-    const uint32_t n_items = end - begin;
-    const uint32_t n_groups = (n_items + RT_BLOCK - 1) / RT_BLOCK;
-    for (uint32_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
-        const uint32_t i = begin + grp * RT_BLOCK + threadIdx.x;
+    for (uint32_t grp = blockIdx.x; grp < G.total; grp += gridDim.x) {
+        uint32_t shard, pos, lim;
+        locate(G, grp, shard, pos, lim);
+        const uint32_t i = pos + threadIdx.x;
         uint4 b = make_uint4(0, 0, 0, 0);
-        if (i < end) b = A.node_b[i];
+        if (i < lim) b = A.node_b[i];
         const bool hit = (b.w & (NODE_HIT | NODE_PARKED)) == NODE_HIT;
         if (!__any(hit)) continue;                                                           // wave-uniform
         float4 hn = make_float4(0, 0, 0, 0), hp = make_float4(0, 0, 0, 0);
@@ -895,8 +1003,12 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade_wide(DScene S, LevelArgs A) 
         int parked;
         shade_ray<false, COUNT>(S, A, i, b, hit, true, f4xyz(hn), f4xyz(hp), hp.w, hn.w, 0, 0, false, mk(0, 0, 0), nullptr, wk,
                                 n_shadow, parked);
-        const uint32_t qslot = wave_append(A.qcount_s + A.level, parked >= 0);
-        if (parked >= 0) A.queue_s[begin + qslot] = make_uint2(i, (uint32_t)parked);
+        if (level0) {       // mark; hit_n.w (tmpdist at the start of the light loop) is not needed again: keep the resume point there
+            if (parked >= 0) { A.node_b[i].w = b.w | NODE_SPARKED; A.hit_n[i].w = __uint_as_float((uint32_t)parked); }
+        } else {
+            const uint32_t qslot = wave_append(A.sc[shard].qs + A.level, parked >= 0);
+            if (parked >= 0) A.queue_s[lane_read(v.start, shard) + qslot] = make_uint2(i, (uint32_t)parked);
+        }
     }
     flush_shadow(A, n_shadow);
     if (COUNT) flush_work(A.work, 1, wk);
@@ -913,33 +1025,43 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade_quad(DScene S, LevelArgs A) 
     const uint32_t quad = threadIdx.x >> 2, j = threadIdx.x & 3u;
     uint32_t* qs = lds_stack + quad;
 
-    uint32_t begin = 0, end = A.n0;
-    if (A.level_hi > 0) level_range(A, A.level, A.level_hi, begin, end);
+    const bool level0 = A.level == 0;                 // then level_hi == 0
+    const ShardView v = shard_view(A, A.level, A.level_hi);
+    Groups G;
+    if (MODE == 0 || level0) {      // MODE 1, 2 at level 0: the marked entries, block by block
+        G = level0 ? make_groups_dense<true>(A.n0, A.chunk_log2) : make_groups<true>(v.start, v.cnt);
+    } else {
+        const ShardCounters* c = A.sc + (lane_id() & (RT_SHARDS - 1u));
+        const uint32_t q = MODE == 1 ? c->qs[A.level] : c->qe[A.level];
+        G = make_groups<true>(v.start, q < v.cnt ? q : v.cnt);
+    }
     Work wk = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (COUNT) { wk.t_start = wall_clock64(); wk.c_start = clock64(); }
     uint32_t n_shadow = 0;
-    uint32_t n_items = end - begin;
-    if (MODE != 0) {
-        const uint32_t q = MODE == 1 ? A.qcount_s[A.level] : A.qcount_e[A.level];
-        n_items = q < end - begin ? q : end - begin;
-    }
-    const uint32_t R = quads_per_wave(n_items);
-    const uint32_t n_groups = (n_items + R - 1) / R;
-    // Workgroup -> group mapping: workgroups whose ids are congruent mod 256 tend to share a CU (ids go round-robin
-    // over the 8 XCDs, then over an XCD's CUs), so they get CONSECUTIVE groups: neighbouring rays, the same part of
-    // the tree, in the same 32-KB L1.
-    const uint32_t per_cu = (n_groups + 255u) >> 8;
+    const uint32_t R = G.R;
+    // Workgroup -> group mapping: see group_of
+    const uint32_t run_log2 = (A.debug >> 8) ? ((A.debug >> 8) & 31u) : RT_RUN_LOG2;
+    const uint32_t rl = run_log2 >= 31u ? 0u : run_log2;
+    const uint32_t per_cu = ((((G.total + 255u) >> 8) + (1u << rl) - 1u) >> rl) << rl;
     for (uint32_t vb = blockIdx.x; vb < per_cu * 256u; vb += gridDim.x) {
-        const uint32_t grp = (vb & 255u) * per_cu + (vb >> 8);
-        if (grp >= n_groups) continue;
-        const uint32_t idx = grp * R + quad;
-        const bool active = quad < R && idx < n_items;
-        uint32_t i = begin + idx, li0 = 0, k0 = 0;
-        if (MODE == 1 && active) {
-            const uint2 e = A.queue_s[begin + idx];
+        const uint32_t grp = group_of(vb, per_cu, run_log2);
+        if (grp >= G.total) continue;
+        uint32_t shard, pos, lim;
+        locate(G, grp, shard, pos, lim);
+        bool active = quad < R && pos + quad < lim;
+        uint32_t i = pos + quad, li0 = 0, k0 = 0;
+        if (MODE != 0 && level0) {
+            const uint32_t il = (pos & ~63u) + lane_id();
+            const uint32_t want = MODE == 1 ? NODE_SPARKED : (NODE_HIT | NODE_PARKED);
+            const unsigned long long marks = __ballot(il < lim && (A.node_b[il].w & want) == want);
+            if ((uint32_t)__popcll(marks) <= (pos & 63u)) continue;                              // wave-uniform
+            active = pick_marked(marks, pos, R, quad, i);
+        } else if (MODE == 1 && active) {
+            const uint2 e = A.queue_s[pos + quad];
             i = e.x; li0 = e.y >> 16; k0 = e.y & 0xFFFFu;
+        } else if (MODE == 2 && active) {
+            i = A.queue_e[pos + quad].x;
         }
-        if (MODE == 2 && active) i = A.queue_e[begin + idx].x;
         uint4 b = make_uint4(0, 0, 0, 0);
         if (active) b = A.node_b[i];
         const bool hit = (b.w & NODE_HIT) != 0;
@@ -950,7 +1072,11 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade_quad(DScene S, LevelArgs A) 
         if (hit) {
             hn = A.hit_n[i]; hp = A.hit_p[i];
             tmpdist = hn.w;
-            if (!FRESH) { const float4 c = A.node_a[i]; color = f4xyz(c); tmpdist = c.w; }
+            if (!FRESH) {
+                const float4 c = A.node_a[i];
+                color = f4xyz(c); tmpdist = c.w;
+                if (level0) { const uint32_t code = __float_as_uint(hn.w); li0 = code >> 16; k0 = code & 0xFFFFu; }
+            }
         }
         if (COUNT) wk.batches++;
         int parked;
@@ -981,9 +1107,14 @@ __global__ void k_set_frame_params(FrameParams p, FrameParams* dst) {
 
 // Fold of one level (>= 1): finishes every node whose children were traced one level deeper.
 __global__ __launch_bounds__(256) void k_fold(DScene S, LevelArgs A) {
-    uint32_t begin, end;
-    level_range(A, A.level, A.level, begin, end);
-    for (uint32_t i = begin + blockIdx.x * 256 + threadIdx.x; i < end; i += gridDim.x * 256) {
+    const ShardView v = shard_view(A, A.level, A.level);
+    const Groups G = make_groups<false>(v.start, v.cnt);
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t grp = blockIdx.x * 4u + (threadIdx.x >> 6); grp < G.total; grp += gridDim.x * 4u) {
+        uint32_t shard, pos, lim;
+        locate(G, grp, shard, pos, lim);
+        const uint32_t i = pos + lane;
+        if (i >= lim) continue;
         const uint4 b = A.node_b[i];
         if (b.w & NODE_FOLD) {
             const V3 c = node_color(S, A.node_a, A.node_b, i);
@@ -992,28 +1123,6 @@ __global__ __launch_bounds__(256) void k_fold(DScene S, LevelArgs A) {
             A.node_a[i] = a;
             A.node_b[i].w = b.w & ~NODE_FOLD;
         }
-    }
-}
-
-// Fold of levels A.level_hi down to A.level by ONE workgroup: one launch instead of one per level, for frames whose
-// cost is the host's launch rate (deep levels hold few nodes). A level's writes are visible to the next iteration
-// after the barrier: the workgroup's waves share an L1.
-__global__ __launch_bounds__(1024) void k_fold_tail(DScene S, LevelArgs A) {
-    for (int lv = A.level_hi; lv >= A.level; --lv) {
-        uint32_t begin, end;
-        level_range(A, lv, lv, begin, end);
-        for (uint32_t i = begin + threadIdx.x; i < end; i += 1024) {
-            const uint4 b = A.node_b[i];
-            if (b.w & NODE_FOLD) {
-                const V3 c = node_color(S, A.node_a, A.node_b, i);
-                float4 a = A.node_a[i];
-                a.x = c.x; a.y = c.y; a.z = c.z;
-                A.node_a[i] = a;
-                A.node_b[i].w = b.w & ~NODE_FOLD;
-            }
-        }
-        __threadfence();
-        __syncthreads();
     }
 }
 
@@ -1188,9 +1297,6 @@ void launch_set_frame_params(const FrameParams& p, FrameParams* dst, hipStream_t
 }
 void launch_fold(const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st) {
     hipLaunchKernelGGL(k_fold, dim3(grid), dim3(256), 0, st, S, A);
-}
-void launch_fold_tail(const DScene& S, const LevelArgs& A, hipStream_t st) {
-    hipLaunchKernelGGL(k_fold_tail, dim3(1), dim3(1024), 0, st, S, A);
 }
 void launch_resolve(const DScene& S, const LevelArgs& A, uint8_t* out, hipStream_t st) {
     const uint32_t npix = A.n0 / A.spp;

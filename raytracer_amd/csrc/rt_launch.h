@@ -47,7 +47,12 @@ struct PixelMap {
     uint32_t pad;
 };
 
-// Pool entry i = one trace() invocation ("node"). Entries [0, n0) are level 0; level k >= 1 follows level k-1.
+// Pool entry i = one trace() invocation ("node"). Entries [0, n0) are level 0 (sample order). The rest of the pool is
+// RT_SHARDS equal sub-pools; in each, level k >= 1 follows level k-1. An entry's shard is fixed for the whole tree:
+// a level-0 entry's by its position (rt_shard_of_level0), a child's is its parent's. Every append counter exists once
+// per shard, 256 B apart: a returning atomic on ONE address costs 11.4 ns on MI355X and they serialise
+// (tools/atomic_rate.cpp: 65,536 one-per-wave appends = 0.75 ms on one counter, 0.02 ms on 64), which made the
+// per-lane level-0 kernels atomic-bound.
 //   k_extend writes  node_b (children, material, flags), hit_n, hit_p for a hit; node_a for a miss
 //   k_shade  writes  node_a for a hit (light loop of trace()), may downgrade node_b.w (the `return red` exit)
 //   k_fold / k_resolve read node_a / node_b
@@ -59,15 +64,27 @@ struct FrameParams {
     DCamera cam;
 };
 
+#define RT_SHARDS 32u
+#define RT_SHARD_CHUNK_LOG2 4u      // level 0: runs of 2^k consecutive 64-entry blocks share a shard (LevelArgs::chunk_log2)
+#define RT_SHARD_CHUNK_LOG2_MAX 8u
+struct ShardCounters {              // 256 B
+    uint32_t level[RT_MAX_LEVELS + 4];  // entries appended per level (index 0 unused)
+    uint32_t qe[RT_MAX_LEVELS + 4];     // per level: rays k_extend_wide queued for k_extend_quad
+    uint32_t qs[RT_MAX_LEVELS + 4];     // per level: hits k_shade_wide queued for k_shade_quad
+    uint32_t pad[64 - 3 * (RT_MAX_LEVELS + 4)];
+};
+static_assert(sizeof(ShardCounters) == 256, "one shard's counters fill 256 bytes");
+static inline __host__ __device__ uint32_t rt_shard_of_level0(uint32_t i, uint32_t chunk_log2) { return (i >> (6u + chunk_log2)) & (RT_SHARDS - 1u); }
+
 struct LevelArgs {
     uint32_t n0;                 // level-0 samples of this pass (multiple of spp)
     int32_t level;               // k_extend / k_fold: the level; k_shade: first level of the range
     int32_t level_hi;            // k_shade: last level of the range (inclusive)
     int32_t max_depth;
     uint32_t spp;
-    uint32_t pool_cap;           // node pool entries (all levels)
+    uint32_t sub_cap;            // entries of one sub-pool; the pool holds n0 + RT_SHARDS * sub_cap
     uint64_t sample0;            // first sample of the pass in the frame's sample order
-    uint32_t* counters;          // [RT_MAX_LEVELS+1] entries appended per level (index 0 unused)
+    ShardCounters* sc;           // [RT_SHARDS]
     uint32_t* cancelled;         // [RT_MAX_LEVELS+1] per level: speculative children whose parent took the red exit
     uint32_t* overflow;          // set to 1 if a child did not fit
     unsigned long long* shadow_count;   // [RT_STAT_SHARDS], indexed by workgroup
@@ -77,16 +94,15 @@ struct LevelArgs {
     uint4* node_b;               // per pool entry: refl child, refr child, material, flags
     float4* hit_n;               // per pool entry with a hit: hitNormal xyz, tmpdist as the closest-hit loop left it
     float4* hit_p;               // per pool entry with a hit: hitPt xyz, rCoef
-    uint2* queue_e;              // per pool entry: rays k_extend_wide suspended {pool entry, object index}; a level's
-                                 // queue starts at the level's pool offset
+    uint2* queue_e;              // levels >= 1: rays k_extend_wide suspended {pool entry, object index}; the queue of
+                                 // (level, shard) starts at the pool offset of that level in that sub-pool. (Level 0
+                                 // keeps no queue: suspended entries are marked in node_b.w, see pick_marked.)
     uint2* queue_s;              // same for k_shade_wide {pool entry, light << 16 | object}
-    uint32_t* qcount_e;          // [RT_MAX_LEVELS+1] queue lengths per level
-    uint32_t* qcount_s;
     const float* aa;             // anti-aliasing pattern (device)
     const float* user_rays;      // SRC 2
     const FrameParams* fp;       // camera + background of the frame (device)
     uint32_t debug;              // timing experiments only (RT_DEBUG_SKIP)
-    uint32_t pad2;
+    uint32_t chunk_log2;         // level-0 shard chunks (RT_SHARD_CHUNK_LOG2; RT_CHUNK_LOG2 in the environment for experiments)
     uint4* wave_log;             // diagnostics (COUNT builds, RT_WAVE_LOG): per workgroup {start, end, traversal ticks, batches}
     PixelMap pm;
 };
@@ -103,7 +119,6 @@ void launch_extend(int src, int form, bool count, const DScene& S, const LevelAr
 void launch_shade(int form, bool count, const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st);
 void launch_set_frame_params(const FrameParams& p, FrameParams* dst, hipStream_t st);
 void launch_fold(const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st);
-void launch_fold_tail(const DScene& S, const LevelArgs& A, hipStream_t st);   // levels A.level..A.level_hi, one workgroup
 void launch_resolve(const DScene& S, const LevelArgs& A, uint8_t* out, hipStream_t st);
 void launch_resolve_rgb(const DScene& S, const LevelArgs& A, float* rgb, hipStream_t st);
 void launch_untile(const UntileArgs& U, const uint8_t* tiles, uint8_t* out, hipStream_t st);

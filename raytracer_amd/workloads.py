@@ -155,6 +155,8 @@ WORKLOADS = {
     "c4_bunny_glass_4k_16spp": (lambda: scene_bunny(59, third="glass2"), 3840, 2160, aa_grid(4), 8),
     # BASELINE config 5 (one GPU renders its 1/n_parts of the tiles; the whole frame on one GPU is the N=1 case)
     "c5_field_10m_8k_64spp": (lambda: scene_field(), 7680, 4320, aa_grid(8), 10),
+    # the 10 M-triangle scene at a frame size counter passes can afford (2 passes of 4 M samples)
+    "c5_field_10m_1080p_4spp": (lambda: scene_field(), 1920, 1080, aa_grid(2), 10),
     # the same scene at a size the tests and a quick look can afford
     "c5_field_small_720p": (lambda: scene_field(64, 8), 1280, 720, (), 10),
 }
