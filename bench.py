@@ -301,8 +301,8 @@ def main():
                     ms0[k] += s2.kernel_ms_by[k]; n0[k] += s2.kernel_launches_by[k]
             dev.render_device(cam, params, frame.data_ptr(), stream=stream)      # leave the full frame in the buffer
             torch.cuda.synchronize()
-            rocprof_names = ("k_extend_wide<0, false>", "k_shade_wide<false>", "k_extend_quad<0, false, false>",
-                             "k_shade_quad<1, false>", "k_shade_quad<2, false>")
+            rocprof_names = ("k_extend_wide<0, false>", "k_shade_wide<false, false>", "k_extend_quad<0, false, false>",
+                             "k_shade_quad<1, false, false>", "k_shade_quad<2, false, false>")
             dk = max(range(NK), key=lambda k: ms0[k] / max(n0[k], 1))
             avg = ms0[dk] / n0[dk]
             lp = n0[dk] / reps

@@ -214,6 +214,11 @@ extern "C" int rt_scene_create(const rt_flat_scene* sc, int device, rt_scene** o
         t.pad0 = t.pad1 = t.pad2 = 0;
     }
     s->d.n_objects = sc->n_objects;
+    s->d.generic_pow = 0;
+    for (uint32_t m = 0; m < sc->n_materials; ++m) {
+        const float e = sc->materials[m].specRefExp;
+        if (!(e >= 0.0f && e <= float(RT_POW_MAX_INT) && float(int(e)) == e)) s->d.generic_pow = 1;
+    }
     s->d.n_lights = sc->n_lights;
     if ((rc = upload(s, objs.data(), objs.size(), &s->d.objects)) != RT_OK) return fail(rc);
     if ((rc = upload(s, models.data(), models.size(), &s->d.models)) != RT_OK) return fail(rc);

@@ -203,6 +203,9 @@ template <int CTRL> __device__ __forceinline__ float dpp_f(float v) { return __u
 #define QP_BCAST(k) ((k) * 0x55)   // every lane of the quad reads lane k
 #define QP_XOR1 0xB1               // [1,0,3,2]
 #define QP_XOR2 0x4E               // [2,3,0,1]
+#define QP_ROT1 0x39               // [1,2,3,0]: lane j reads lane j+1
+#define QP_ROT2 0x4E               // [2,3,0,1]
+#define QP_ROT3 0x93               // [3,0,1,2]
 __device__ __forceinline__ uint32_t quad_max_u(uint32_t v) {
     v = max(v, dpp_u<QP_XOR1>(v));
     return max(v, dpp_u<QP_XOR2>(v));
@@ -250,10 +253,12 @@ __device__ __forceinline__ void quad_traverse(const DScene& S, uint32_t root, bo
             tn = h ? tn : FLT_MAX;
             const uint32_t bits = quad_bits(h, lane);
             const uint32_t n_hit = (uint32_t)__popc(bits);
-            // rank of this lane's child among the hit ones, nearest first (ties: lower slot first)
-            const float t0 = dpp_f<QP_BCAST(0)>(tn), t1 = dpp_f<QP_BCAST(1)>(tn), t2 = dpp_f<QP_BCAST(2)>(tn), t3 = dpp_f<QP_BCAST(3)>(tn);
-            const uint32_t rank = (uint32_t)(t0 < tn || (t0 == tn && 0u < j)) + (uint32_t)(t1 < tn || (t1 == tn && 1u < j)) +
-                                  (uint32_t)(t2 < tn || (t2 == tn && 2u < j)) + (uint32_t)(t3 < tn);
+            // rank of this lane's child among the hit ones, nearest first. tn >= 0, so its bit pattern orders like its
+            // value; with the slot in the two lowest bits the four keys are distinct (the visiting order only affects
+            // how much is culled, never the result: see tcull)
+            const uint32_t key = (__float_as_uint(tn) & ~3u) | j;
+            const uint32_t rank = (uint32_t)(dpp_u<QP_ROT1>(key) < key) + (uint32_t)(dpp_u<QP_ROT2>(key) < key) +
+                                  (uint32_t)(dpp_u<QP_ROT3>(key) < key);
             // the nearest is visited next, the others are pushed so that the second nearest is on top
             if (h && rank > 0) qs[(sp + (int)n_hit - 1 - (int)rank) * 16] = ref;
             cur = quad_max_u((h && rank == 0) ? ref : 0u);     // a child reference is never 0 (node 0 is a root)
@@ -443,9 +448,12 @@ __device__ __forceinline__ bool occluded_loop(const DScene& S, const Ray& ray, b
 // double roundings (relative error < 1e-15), which the narrowing to float that follows absorbs except when the value
 // sits within that distance of a float rounding boundary (probability ~1e-8 per call; libm's and the device
 // library's pow differ from each other by as much). Other exponents go to the device pow.
+// GPOW = false: the scene holds integer exponents only (DScene::generic_pow, decided when the scene is created); the
+// device pow is then not part of the kernel, which halves k_shade_wide's registers (119 -> 63 VGPRs).
+template <bool GPOW>
 __device__ __forceinline__ double spec_pow(double x, float e) {
     const int n = (int)e;
-    if ((float)n == e && n >= 0 && n <= 64) {
+    if (!GPOW || ((float)n == e && n >= 0 && n <= RT_POW_MAX_INT)) {
         double r = 1.0, b = x;
         for (int k = n; k; k >>= 1) { if (k & 1) r *= b; b *= b; }
         return r;
@@ -541,6 +549,20 @@ __device__ __forceinline__ bool map_pixel(const PixelMap& pm, uint64_t q, uint32
 //   SRC 0: level 0, rays generated from the camera     SRC 1: level >= 1, rays read from the pool
 //   SRC 2: level 0, rays supplied by the caller (rt_trace)
 // ---------------------------------------------------------------------------------------------------------
+// Waves per SIMD the register allocator must leave room for (512 VGPRs per lane: 4 waves = 128 VGPRs each, ...). The
+// traversal is a chain of dependent loads, so more resident waves pay even where a few values spill to scratch.
+#ifndef RT_WPE_SQ
+#define RT_WPE_SQ 4
+#endif
+#ifndef RT_WPE_EQ
+#define RT_WPE_EQ 5
+#endif
+#ifndef RT_WPE_SW
+#define RT_WPE_SW 4
+#endif
+#ifndef RT_WPE_EW
+#define RT_WPE_EW 7
+#endif
 #define RT_RUN_LOG2 3u    // see group_of: runs of 8 groups (measured: 1, 2, 4 and 16 within 3 %; 64+ and one strip per CU 5-20 % slower). Experiments: RT_DEBUG_SKIP = run_log2 << 8
 #define NODE_HIT 4u      // has a hit record: k_shade computes its colour
 #define NODE_PARKED 8u   // the ray was suspended by k_extend_wide and finished by k_extend_quad: its hit is shaded by
@@ -809,7 +831,7 @@ __device__ __forceinline__ void locate(const Groups& G, uint32_t grp, uint32_t& 
 
 // k_extend_wide: one ray per lane. Rays that never reach a mesh are finished here; the others are queued.
 template <int SRC, bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) void k_extend_wide(DScene S, LevelArgs A) {
+__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WPE_EW))) void k_extend_wide(DScene S, LevelArgs A) {
     const bool level0 = SRC != 1;
     const ShardView v = shard_view(A, A.level, A.level);
     const Groups G = level0 ? make_groups_dense<false>(A.n0, A.chunk_log2) : make_groups<false>(v.start, v.cnt);
@@ -847,7 +869,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_wide(DScene S, LevelArgs A)
 // k_extend_quad: one ray per quad. FRESH: all rays of the level from the start (levels with few rays: no per-lane
 // kernel runs for them). !FRESH: the rays k_extend_wide queued, resumed at the mesh they stopped at.
 template <int SRC, bool FRESH, bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) void k_extend_quad(DScene S, LevelArgs A) {
+__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WPE_EQ))) void k_extend_quad(DScene S, LevelArgs A) {
     __shared__ uint32_t lds_stack[RT_QSTACK * 16];
     const uint32_t quad = threadIdx.x >> 2, j = threadIdx.x & 3u;
     uint32_t* qs = lds_stack + quad;
@@ -913,7 +935,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_extend_quad(DScene S, LevelArgs A)
 // Light loop of trace() (reference src/raytracer.cpp:311-345) for one hit, starting at light li0 / object k0 of its
 // shadow loop (0/0, or where the per-lane kernel suspended). Writes node_a[i]; on suspension (QUAD = false) node_a[i]
 // holds {colour so far, tmpdist} and `parked` gets (li << 16) | k. Convergent.
-template <bool QUAD, bool COUNT>
+template <bool QUAD, bool COUNT, bool GPOW>
 __device__ __forceinline__ void shade_ray(const DScene& S, const LevelArgs& A, uint32_t i, uint4 b, bool hit, bool writer,
                                           V3 hitNormal, V3 hitPt, float rCoef, float tmpdist, uint32_t li0, uint32_t k0,
                                           bool resumed, V3 color, uint32_t* qs, Work& wk, uint32_t& n_shadow, int& parked) {
@@ -947,7 +969,7 @@ __device__ __forceinline__ void shade_ray(const DScene& S, const LevelArgs& A, u
         color = color + mk(((mc.x * lc.x) * mk4.x) * fd, ((mc.y * lc.y) * mk4.x) * fd, ((mc.z * lc.z) * mk4.x) * fd);
         const V3 reflectRay = (hitNormal * 2.0f) * dot(hitNormal, lv) - lv;
         const float cosAlpha = max_std(dot(reflectRay, lv), 0.0f);
-        const float fs = (float)(spec_pow((double)cosAlpha, specRefExp) / (double)(ldist * ldist));
+        const float fs = (float)(spec_pow<GPOW>((double)cosAlpha, specRefExp) / (double)(ldist * ldist));
         color = color + mk((lc.x * mk4.y) * fs, (lc.y * mk4.y) * fs, (lc.z * mk4.y) * fs);
     }
     if (!hit || !writer) return;
@@ -982,8 +1004,8 @@ __device__ __forceinline__ void flush_shadow(const LevelArgs& A, uint32_t n_shad
 
 // k_shade_wide: light loop, one hit per lane, for the hits of levels A.level..A.level_hi. Hits whose shadow rays never
 // reach a mesh are finished here; the others are queued (queue of A.level) at the point they stopped.
-template <bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) void k_shade_wide(DScene S, LevelArgs A) {
+template <bool COUNT, bool GPOW>
+__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WPE_SW))) void k_shade_wide(DScene S, LevelArgs A) {
     const bool level0 = A.level == 0;                 // then level_hi == 0: level 0 is not part of a range
     const ShardView v = shard_view(A, A.level, A.level_hi);
     const Groups G = level0 ? make_groups_dense<false>(A.n0, A.chunk_log2) : make_groups<false>(v.start, v.cnt);
@@ -1001,7 +1023,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade_wide(DScene S, LevelArgs A) 
         float4 hn = make_float4(0, 0, 0, 0), hp = make_float4(0, 0, 0, 0);
         if (hit) { hn = A.hit_n[i]; hp = A.hit_p[i]; }
         int parked;
-        shade_ray<false, COUNT>(S, A, i, b, hit, true, f4xyz(hn), f4xyz(hp), hp.w, hn.w, 0, 0, false, mk(0, 0, 0), nullptr, wk,
+        shade_ray<false, COUNT, GPOW>(S, A, i, b, hit, true, f4xyz(hn), f4xyz(hp), hp.w, hn.w, 0, 0, false, mk(0, 0, 0), nullptr, wk,
                                 n_shadow, parked);
         if (level0) {       // mark; hit_n.w (tmpdist at the start of the light loop) is not needed again: keep the resume point there
             if (parked >= 0) { A.node_b[i].w = b.w | NODE_SPARKED; A.hit_n[i].w = __uint_as_float((uint32_t)parked); }
@@ -1018,8 +1040,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade_wide(DScene S, LevelArgs A) 
 //   MODE 0  all hits of levels A.level..A.level_hi, from the start
 //   MODE 1  the hits k_shade_wide queued (queue_s of A.level), resumed where they stopped
 //   MODE 2  the hits of the rays that went through the extend queue (queue_e of A.level), from the start
-template <int MODE, bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) void k_shade_quad(DScene S, LevelArgs A) {
+template <int MODE, bool COUNT, bool GPOW>
+__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WPE_SQ))) void k_shade_quad(DScene S, LevelArgs A) {
     constexpr bool FRESH = MODE != 1;
     __shared__ uint32_t lds_stack[RT_QSTACK * 16];
     const uint32_t quad = threadIdx.x >> 2, j = threadIdx.x & 3u;
@@ -1080,7 +1102,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade_quad(DScene S, LevelArgs A) 
         }
         if (COUNT) wk.batches++;
         int parked;
-        shade_ray<true, COUNT>(S, A, i, b, hit, j == 0, f4xyz(hn), f4xyz(hp), hp.w, tmpdist, li0, k0, !FRESH, color, qs, wk,
+        shade_ray<true, COUNT, GPOW>(S, A, i, b, hit, j == 0, f4xyz(hn), f4xyz(hp), hp.w, tmpdist, li0, k0, !FRESH, color, qs, wk,
                                n_shadow, parked);
     }
     flush_shadow(A, n_shadow);
@@ -1276,21 +1298,17 @@ void launch_extend(int src, int form, bool count, const DScene& S, const LevelAr
     else if (src == 1) launch_extend_src<1>(form, count, S, A, dim3(grid), st);
     else launch_extend_src<2>(form, count, S, A, dim3(grid), st);
 }
+template <bool COUNT, bool GPOW>
+static void launch_shade_t(int form, const DScene& S, const LevelArgs& A, dim3 g, dim3 b, hipStream_t st) {
+    if (form == RT_FORM_WIDE) hipLaunchKernelGGL((k_shade_wide<COUNT, GPOW>), g, b, 0, st, S, A);
+    else if (form == RT_FORM_QUAD_FRESH) hipLaunchKernelGGL((k_shade_quad<0, COUNT, GPOW>), g, b, 0, st, S, A);
+    else if (form == RT_FORM_QUAD_RESUME) hipLaunchKernelGGL((k_shade_quad<1, COUNT, GPOW>), g, b, 0, st, S, A);
+    else hipLaunchKernelGGL((k_shade_quad<2, COUNT, GPOW>), g, b, 0, st, S, A);
+}
 void launch_shade(int form, bool count, const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st) {
     dim3 g(grid), b(RT_BLOCK);
-    if (form == RT_FORM_WIDE) {
-        if (count) hipLaunchKernelGGL((k_shade_wide<true>), g, b, 0, st, S, A);
-        else hipLaunchKernelGGL((k_shade_wide<false>), g, b, 0, st, S, A);
-    } else if (form == RT_FORM_QUAD_FRESH) {
-        if (count) hipLaunchKernelGGL((k_shade_quad<0, true>), g, b, 0, st, S, A);
-        else hipLaunchKernelGGL((k_shade_quad<0, false>), g, b, 0, st, S, A);
-    } else if (form == RT_FORM_QUAD_RESUME) {
-        if (count) hipLaunchKernelGGL((k_shade_quad<1, true>), g, b, 0, st, S, A);
-        else hipLaunchKernelGGL((k_shade_quad<1, false>), g, b, 0, st, S, A);
-    } else {
-        if (count) hipLaunchKernelGGL((k_shade_quad<2, true>), g, b, 0, st, S, A);
-        else hipLaunchKernelGGL((k_shade_quad<2, false>), g, b, 0, st, S, A);
-    }
+    if (S.generic_pow) { if (count) launch_shade_t<true, true>(form, S, A, g, b, st); else launch_shade_t<false, true>(form, S, A, g, b, st); }
+    else { if (count) launch_shade_t<true, false>(form, S, A, g, b, st); else launch_shade_t<false, false>(form, S, A, g, b, st); }
 }
 void launch_set_frame_params(const FrameParams& p, FrameParams* dst, hipStream_t st) {
     hipLaunchKernelGGL(k_set_frame_params, dim3(1), dim3(64), 0, st, p, dst);

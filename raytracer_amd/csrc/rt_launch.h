@@ -17,7 +17,7 @@ struct DScene {
     uint32_t n_objects;
     uint32_t n_lights;
     uint32_t debug;              // timing experiments only (RT_DEBUG_SKIP)
-    uint32_t pad;
+    uint32_t generic_pow;        // a material's specRefExp is not an integer in [0, RT_POW_MAX_INT]: shade kernels with pow()
     const DModel* models;
     const rt_material* materials;
     const float4* lights;        // 2 per light: pos, color
@@ -64,6 +64,7 @@ struct FrameParams {
     DCamera cam;
 };
 
+#define RT_POW_MAX_INT 64
 #define RT_SHARDS 32u
 #define RT_SHARD_CHUNK_LOG2 4u      // level 0: runs of 2^k consecutive 64-entry blocks share a shard (LevelArgs::chunk_log2)
 #define RT_SHARD_CHUNK_LOG2_MAX 8u

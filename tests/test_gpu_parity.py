@@ -96,6 +96,23 @@ def test_trace_colours(oracle_mod, third, depth):
     assert same >= 0.999
 
 
+def test_generic_pow_exponent(oracle_mod):
+    """A material with a non-integer specRefExp takes the shade kernels built with the device pow (DScene::generic_pow);
+    scene.yaml's materials (exponent 8) take the ones without it."""
+    O = oracle_mod
+    fs = wl.scene_bunny(8)
+    for m in fs.materials:
+        m.specRefExp = 7.5
+    dev = DeviceScene(fs)
+    cam = reference_camera(200, 150)
+    p = Params()
+    rays = camera_rays(O, cam, p, 1)
+    got, st1 = dev.trace(p, rays)
+    want, st2 = O.Oracle(fs).trace(p, rays)
+    assert st1.trace_calls == st2.trace_calls and st1.shadow_rays == st2.shadow_rays
+    assert np.abs(got - want).max() <= 2e-6
+
+
 @pytest.mark.parametrize("case", ["analytic_1spp", "analytic_9spp", "glass2", "mesh", "mesh_glass2_depth8", "mesh_rect", "field"])
 def test_frame_parity(oracle_mod, case):
     O = oracle_mod
