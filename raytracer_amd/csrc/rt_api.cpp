@@ -62,6 +62,7 @@ enum { RT_K_EXTEND_WIDE = 0, RT_K_SHADE_WIDE = 1, RT_K_EXTEND_QUAD = 2, RT_K_SHA
 struct rt_scene {
     int device = 0;
     hipStream_t stream = nullptr;
+    int n_shade_streams = 3;             // RT_SHADE_STREAMS in the environment (experiments): 1..3
     hipStream_t shade_stream[3] = {nullptr, nullptr, nullptr};   // the shade kernels run here, next to the extend kernels:
                                                                  // large levels on [level & 1], runs of small levels on [2]
     hipEvent_t ev_sync[2 * RT_MAX_LEVELS + 5] = {};      // per level: per-lane extend done, quad extend done; joins
@@ -169,6 +170,7 @@ extern "C" int rt_scene_create(const rt_flat_scene* sc, int device, rt_scene** o
         hipStreamCreateWithFlags(&s->shade_stream[0], hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&s->shade_stream[1], hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&s->shade_stream[2], hipStreamNonBlocking) != hipSuccess) { rt_set_error("hipStreamCreate failed"); return fail(RT_ERR_DEVICE); }
+    if (const char* e = std::getenv("RT_SHADE_STREAMS")) s->n_shade_streams = std::max(1, std::min(3, std::atoi(e)));
     for (hipEvent_t& e : s->ev_sync)
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { rt_set_error("hipEventCreate failed"); return fail(RT_ERR_DEVICE); }
 
@@ -455,7 +457,7 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
         }
         // shade launch `form` over levels lo..hi on the level's shade stream, after event `after` of stream A
         auto shade = [&](int form, int lo, int hi, int after) -> int {
-            const int which = form == RT_FORM_QUAD_FRESH ? 2 : (lo & 1);
+            const int which = (form == RT_FORM_QUAD_FRESH ? 2 : (lo & 1)) % s->n_shade_streams;
             hipStream_t sb = overlap ? s->shade_stream[which] : sa;
             if (overlap) {
                 if (last_wait[which] != after) HIP_TRY(hipStreamWaitEvent(sb, s->ev_sync[after], 0));
