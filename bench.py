@@ -101,6 +101,8 @@ def main():
                     help="rehearsal only: every rank uses GPU 0 (needs --backend gloo)")
     ap.add_argument("--frames-in-flight", type=int, default=2,
                     help="frames rendered concurrently (each in its own scene workspace and stream); 1 = one at a time")
+    ap.add_argument("--bvh", default="host", choices=("host", "device"),
+                    help="BVH builder: the host's SAH tree (default) or the GPU's linear BVH (RT_SCENE_BVH_DEVICE)")
     ap.add_argument("--watchdog", type=int, default=0, help="dump all Python stacks and exit after this many seconds")
     args = ap.parse_args()
     if args.watchdog:
@@ -131,7 +133,7 @@ def main():
 
     fs, cam, params = wl.make_workload(args.workload)
     t0 = time.time()
-    dev = DeviceScene(fs, device=local)
+    dev = DeviceScene(fs, device=local, bvh=args.bvh)
     build_s = time.time() - t0
     lib = dev.lib
     W, H = cam.imWidth, cam.imHeight
@@ -145,7 +147,7 @@ def main():
     slots = []
     for k in range(max(1, args.frames_in_flight)):
         sl = Slot()
-        sl.dev = dev if k == 0 else DeviceScene(fs, device=local)
+        sl.dev = dev if k == 0 else DeviceScene(fs, device=local, bvh=args.bvh)
         # the scene's own stream, seen by torch: renders, the RCCL gather and the untile are ordered on it
         sl.stream = torch.cuda.ExternalStream(sl.dev.stream(), device=torch.device("cuda", local))
         sl.frame = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
@@ -223,7 +225,8 @@ def main():
                        "level_rays": [int(x) for x in st.level_rays[:params.c.max_depth + 1]],
                        "parallelism": "1 GPU" if world == 1 else f"{world} GPUs: {tw}x{th} tiles round-robin, RCCL gather",
                        "mesh": "procedural geodesic blob (no .ply ships with the reference)",
-                       "scene_build_s": round(build_s, 3)},
+                       "scene_build_s": round(build_s, 3), "bvh": args.bvh,
+                       "bvh_build_s": round(dev.bvh_info().build_seconds, 4)},
         }
         used = slots[:min(len(slots), args.steps + args.warmup)]
         identical = all(bool(torch.equal(sl.frame, ref_frame)) for sl in used)

@@ -140,6 +140,12 @@ typedef struct rt_scene rt_scene;   /* opaque; owns the HBM copy of the scene on
 /* Replaces: Scene ownership of objects/lights (reference src/scene.h:29-39) on the device side.
  * Builds the BVH on the host (one per Model) and uploads the SoA scene to `device`. */
 int rt_scene_create(const rt_flat_scene* scene, int device, rt_scene** out);
+/* The same with options. RT_SCENE_BVH_DEVICE: build the BVHs on the GPU (linear BVH from Morton order: milliseconds
+ * instead of seconds for millions of faces, frames some tens of percent slower than with the host's SAH tree; a model
+ * whose tree would be too deep for the traversal stack silently gets the host builder). Results are the same with
+ * either tree. No counterpart in the reference. */
+#define RT_SCENE_BVH_DEVICE 1u
+int rt_scene_create_ex(const rt_flat_scene* scene, int device, uint32_t flags, rt_scene** out);
 void rt_scene_destroy(rt_scene* scene);
 
 /* Replaces: render() (reference src/raytracer.cpp:422-463) for the rectangle [x0,x0+w) x [y0,y0+h).
@@ -212,8 +218,9 @@ typedef struct rt_bvh_info {
     uint32_t max_depth;
     uint32_t node_bytes;
     uint32_t tri_bytes;
-    uint32_t reserved;
+    uint32_t built_on_device; /* 1: RT_SCENE_BVH_DEVICE took effect */
     uint64_t device_bytes;   /* total HBM held by the scene */
+    double build_seconds;    /* BVH build (device builder: vertex upload included) */
 } rt_bvh_info;
 int rt_scene_bvh_info(const rt_scene* scene, rt_bvh_info* out);
 
@@ -229,6 +236,9 @@ typedef struct rt_bvh_check_result {
     double build_seconds;
 } rt_bvh_check_result;
 int rt_bvh_check(const rt_flat_scene* scene, rt_bvh_check_result* out);
+/* The same walk over the tree a scene actually holds in HBM (copied back), whichever builder made it; `flat` must be
+ * the scene it was created from. build_seconds is the scene's. */
+int rt_scene_bvh_check(const rt_scene* scene, const rt_flat_scene* flat, rt_bvh_check_result* out);
 
 /* Traversal work of the last call that passed a non-NULL stats AND had counting enabled with
  * rt_set_count_work(1): node visits / triangle tests / sphere / plane tests summed over all rays, per kernel:

@@ -11,6 +11,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "librt_amd.so")
 
+RT_SCENE_BVH_DEVICE = 1
 RT_OBJ_SPHERE, RT_OBJ_PLANE, RT_OBJ_MODEL = 0, 1, 2
 
 
@@ -76,8 +77,8 @@ class rt_stats(C.Structure):
 
 class rt_bvh_info(C.Structure):
     _fields_ = [("n_nodes", C.c_uint32), ("n_faces", C.c_uint32), ("max_depth", C.c_uint32),
-                ("node_bytes", C.c_uint32), ("tri_bytes", C.c_uint32), ("reserved", C.c_uint32),
-                ("device_bytes", C.c_uint64)]
+                ("node_bytes", C.c_uint32), ("tri_bytes", C.c_uint32), ("built_on_device", C.c_uint32),
+                ("device_bytes", C.c_uint64), ("build_seconds", C.c_double)]
 
 
 class rt_bvh_check_result(C.Structure):
@@ -104,9 +105,9 @@ def u8ptr(a):
 
 # Every symbol include/raytracer_amd.h declares; tests check the library exports all of them.
 EXPORTS = [
-    "rt_scene_create", "rt_scene_destroy", "rt_render", "rt_render_device", "rt_render_tiles_device",
+    "rt_scene_create", "rt_scene_create_ex", "rt_scene_destroy", "rt_render", "rt_render_device", "rt_render_tiles_device",
     "rt_tiles_owned", "rt_untile_device", "rt_cast_rays", "rt_intersect", "rt_occluded", "rt_trace",
-    "rt_scene_bvh_info", "rt_bvh_check", "rt_scene_stream", "rt_set_count_work", "rt_get_work", "rt_last_error", "rt_version",
+    "rt_scene_bvh_info", "rt_bvh_check", "rt_scene_bvh_check", "rt_scene_stream", "rt_set_count_work", "rt_get_work", "rt_last_error", "rt_version",
 ]
 
 HOST_EXPORTS = [
@@ -132,6 +133,7 @@ def load(path=None):
     vp = C.c_void_p
     u32 = C.c_uint32
     lib.rt_scene_create.argtypes = [C.POINTER(rt_flat_scene), C.c_int, C.POINTER(vp)]
+    lib.rt_scene_create_ex.argtypes = [C.POINTER(rt_flat_scene), C.c_int, C.c_uint32, C.POINTER(vp)]
     lib.rt_scene_destroy.argtypes = [vp]
     lib.rt_scene_destroy.restype = None
     lib.rt_render.argtypes = [vp, C.POINTER(rt_camera), C.POINTER(rt_params), u32, u32, u32, u32,
@@ -150,6 +152,7 @@ def load(path=None):
     lib.rt_trace.argtypes = [vp, C.POINTER(rt_params), FP, u32, FP, C.POINTER(rt_stats)]
     lib.rt_scene_bvh_info.argtypes = [vp, C.POINTER(rt_bvh_info)]
     lib.rt_bvh_check.argtypes = [C.POINTER(rt_flat_scene), C.POINTER(rt_bvh_check_result)]
+    lib.rt_scene_bvh_check.argtypes = [vp, C.POINTER(rt_flat_scene), C.POINTER(rt_bvh_check_result)]
     lib.rt_scene_stream.argtypes = [vp]
     lib.rt_scene_stream.restype = C.c_void_p
     lib.rt_set_count_work.argtypes = [vp, C.c_int]

@@ -388,6 +388,23 @@ struct Checker {
 };
 }  // namespace
 
+// Walks a finished tree (host arrays) and fills `out` (everything but build_seconds).
+void bvh_walk_check(const rt_flat_scene* sc, const BvhBuildResult& r, rt_bvh_check_result* out) {
+    Checker C{sc, &r, std::vector<uint8_t>(sc->n_faces, 0)};
+    for (uint32_t m = 0; m < sc->n_models; ++m) {
+        const rt_model& md = sc->models[m];
+        if (md.num_faces == 0) { if (r.model_root[m] != RT_NO_CHILD) ++C.errors; continue; }
+        C.walk(r.model_root[m], md, 0);
+        for (uint32_t f = md.first_face; f < md.first_face + md.num_faces; ++f) if (C.seen[f] != 1) ++C.errors;
+    }
+    if (C.depth_seen > r.max_depth) ++C.errors;      // (the device builder reports a bound, the host builder the exact depth)
+    if (r.max_stack > RT_QSTACK) ++C.errors;
+    out->n_nodes = r.n_nodes; out->n_leaves = r.n_leaves; out->n_faces = sc->n_faces;
+    out->max_depth = r.max_depth; out->max_stack = r.max_stack;
+    out->errors = C.errors;
+    out->host_bytes = uint64_t(r.n_nodes) * sizeof(Bvh4Node) + uint64_t(r.n_leaves) * sizeof(LeafBlock);
+}
+
 extern "C" int rt_bvh_check(const rt_flat_scene* sc, rt_bvh_check_result* out) {
     if (!sc || !out) return RT_ERR_INVALID;
     std::memset(out, 0, sizeof *out);
@@ -396,19 +413,7 @@ extern "C" int rt_bvh_check(const rt_flat_scene* sc, rt_bvh_check_result* out) {
     const int rc = bvh_build(sc, &r);
     out->build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (rc != 0) return RT_ERR_INVALID;
-    Checker C{sc, &r, std::vector<uint8_t>(sc->n_faces, 0)};
-    for (uint32_t m = 0; m < sc->n_models; ++m) {
-        const rt_model& md = sc->models[m];
-        if (md.num_faces == 0) { if (r.model_root[m] != RT_NO_CHILD) ++C.errors; continue; }
-        C.walk(r.model_root[m], md, 0);
-        for (uint32_t f = md.first_face; f < md.first_face + md.num_faces; ++f) if (C.seen[f] != 1) ++C.errors;
-    }
-    if (C.depth_seen != r.max_depth) ++C.errors;
-    if (r.max_stack > RT_QSTACK) ++C.errors;
-    out->n_nodes = r.n_nodes; out->n_leaves = r.n_leaves; out->n_faces = sc->n_faces;
-    out->max_depth = r.max_depth; out->max_stack = r.max_stack;
-    out->errors = C.errors;
-    out->host_bytes = uint64_t(r.n_nodes) * sizeof(Bvh4Node) + uint64_t(r.n_leaves) * sizeof(LeafBlock);
+    bvh_walk_check(sc, r, out);
     bvh_free(&r);
     return RT_OK;
 }

@@ -10,12 +10,14 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <vector>
 
 #include "raytracer_amd.h"
 #include "rt_device.h"
 #include "rt_launch.h"
+#include "bvh_device.h"
 
 // ---------------------------------------------------------------------------------------------------------
 // errors
@@ -73,6 +75,10 @@ struct rt_scene {
     bool has_bounce = false;           // some object's material is reflective or refractive
     // workspace
     uint32_t pool_cap = 0, sub_cap = 0, ws_n0 = 0;
+    uint32_t n_leaves = 0, bvh_stack = 0;
+    bool built_on_device = false;
+    double build_seconds = 0;
+    std::vector<uint32_t> model_roots;
     float4* node_a = nullptr;
     uint4* node_b = nullptr;
     float4* rays = nullptr;
@@ -148,7 +154,9 @@ static int validate(const rt_flat_scene* sc) {
     return RT_OK;
 }
 
-extern "C" int rt_scene_create(const rt_flat_scene* sc, int device, rt_scene** out) {
+extern "C" int rt_scene_create(const rt_flat_scene* sc, int device, rt_scene** out) { return rt_scene_create_ex(sc, device, 0u, out); }
+
+extern "C" int rt_scene_create_ex(const rt_flat_scene* sc, int device, uint32_t flags, rt_scene** out) {
     if (!out) { rt_set_error("out is NULL"); return RT_ERR_INVALID; }
     *out = nullptr;
     int rc = validate(sc);
@@ -159,11 +167,21 @@ extern "C" int rt_scene_create(const rt_flat_scene* sc, int device, rt_scene** o
     HIP_TRY(hipSetDevice(device));
 
     BvhBuildResult bvh;
-    if (bvh_build(sc, &bvh) != 0) { rt_set_error("BVH build failed"); return RT_ERR_INVALID; }
+    std::memset(&bvh, 0, sizeof bvh);
+    DeviceBvh dbvh;
+    bool on_device = false;
+    const auto t_build = std::chrono::steady_clock::now();
+    if ((flags & RT_SCENE_BVH_DEVICE) && sc->n_faces) {
+        const int brc = bvh_build_device(sc, &dbvh);
+        if (brc < 0) return RT_ERR_DEVICE;
+        on_device = brc == 0;
+    }
+    if (!on_device && bvh_build(sc, &bvh) != 0) { rt_set_error("BVH build failed"); return RT_ERR_INVALID; }
+    const double build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_build).count();
 
     rt_scene* s = new rt_scene();
     s->device = device;
-    auto fail = [&](int code) { bvh_free(&bvh); free_scene(s); return code; };
+    auto fail = [&](int code) { bvh_free(&bvh); hipFree(dbvh.nodes); hipFree(dbvh.leaves); free_scene(s); return code; };
     // (no stream priorities: low-priority shade streams gained ~1.5 % but hung hipDeviceSynchronize when two processes
     // shared one GPU)
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess ||
@@ -202,7 +220,7 @@ extern "C" int rt_scene_create(const rt_flat_scene* sc, int device, rt_scene** o
     std::vector<DModel> models(sc->n_models);
     for (uint32_t m = 0; m < sc->n_models; ++m) {
         DModel& d = models[m];
-        d.root = bvh.model_root[m];
+        d.root = on_device ? dbvh.model_root[m] : bvh.model_root[m];
         d.first_face = sc->models[m].first_face;
         d.num_faces = sc->models[m].num_faces;
         std::memcpy(d.bb_center, sc->models[m].bb_center, sizeof d.bb_center);
@@ -226,13 +244,24 @@ extern "C" int rt_scene_create(const rt_flat_scene* sc, int device, rt_scene** o
     if ((rc = upload(s, models.data(), models.size(), &s->d.models)) != RT_OK) return fail(rc);
     if ((rc = upload(s, sc->materials, size_t(sc->n_materials), &s->d.materials)) != RT_OK) return fail(rc);
     if ((rc = upload(s, li.data(), li.size(), &s->d.lights)) != RT_OK) return fail(rc);
-    if ((rc = upload(s, bvh.nodes, size_t(bvh.n_nodes), &s->d.nodes)) != RT_OK) return fail(rc);
-    if ((rc = upload(s, bvh.leaves, size_t(bvh.n_leaves), &s->d.leaves)) != RT_OK) return fail(rc);
+    if (on_device) {        // the builder's arrays are the scene's
+        s->owned.push_back(dbvh.nodes); s->owned.push_back(dbvh.leaves);
+        s->d.nodes = dbvh.nodes; s->d.leaves = dbvh.leaves;
+        s->scene_bytes += sizeof(Bvh4Node) * size_t(dbvh.n_nodes) + sizeof(LeafBlock) * size_t(dbvh.n_leaves);
+        s->n_nodes = dbvh.n_nodes; s->n_leaves = dbvh.n_leaves; s->bvh_depth = dbvh.max_depth; s->bvh_stack = dbvh.max_stack;
+        dbvh.nodes = nullptr; dbvh.leaves = nullptr;
+    } else {
+        if ((rc = upload(s, bvh.nodes, size_t(bvh.n_nodes), &s->d.nodes)) != RT_OK) return fail(rc);
+        if ((rc = upload(s, bvh.leaves, size_t(bvh.n_leaves), &s->d.leaves)) != RT_OK) return fail(rc);
+        s->n_nodes = bvh.n_nodes; s->n_leaves = bvh.n_leaves; s->bvh_depth = bvh.max_depth; s->bvh_stack = bvh.max_stack;
+    }
     if ((rc = upload(s, nrm.data(), nrm.size(), &s->d.normals)) != RT_OK) return fail(rc);
     s->n_models = sc->n_models;
     s->n_faces = sc->n_faces;
-    s->n_nodes = bvh.n_nodes;
-    s->bvh_depth = bvh.max_depth;
+    s->built_on_device = on_device;
+    s->build_seconds = build_seconds;
+    s->model_roots.resize(sc->n_models);
+    for (uint32_t m = 0; m < sc->n_models; ++m) s->model_roots[m] = models[m].root;
     bvh_free(&bvh);
 
     if (hipMalloc(reinterpret_cast<void**>(&s->d_counters), sizeof(PassCounters) * RT_MAX_PASSES) != hipSuccess ||
@@ -258,8 +287,27 @@ extern "C" void* rt_scene_stream(const rt_scene* s) { return s ? static_cast<voi
 extern "C" int rt_scene_bvh_info(const rt_scene* s, rt_bvh_info* out) {
     if (!s || !out) { rt_set_error("null argument"); return RT_ERR_INVALID; }
     out->n_nodes = s->n_nodes; out->n_faces = s->n_faces; out->max_depth = s->bvh_depth;
-    out->node_bytes = sizeof(Bvh4Node); out->tri_bytes = sizeof(LeafBlock) / 4; out->reserved = 0;
+    out->node_bytes = sizeof(Bvh4Node); out->tri_bytes = sizeof(LeafBlock) / 4; out->built_on_device = s->built_on_device ? 1u : 0u;
     out->device_bytes = s->scene_bytes;
+    out->build_seconds = s->build_seconds;
+    return RT_OK;
+}
+
+extern "C" int rt_scene_bvh_check(const rt_scene* s, const rt_flat_scene* flat, rt_bvh_check_result* out) {
+    if (!s || !flat || !out) { rt_set_error("null argument"); return RT_ERR_INVALID; }
+    if (flat->n_faces != s->n_faces || flat->n_models != s->n_models) { rt_set_error("not the scene this rt_scene was created from"); return RT_ERR_INVALID; }
+    std::memset(out, 0, sizeof *out);
+    HIP_TRY(hipSetDevice(s->device));
+    std::vector<Bvh4Node> nodes(std::max<uint32_t>(1, s->n_nodes));
+    std::vector<LeafBlock> leaves(std::max<uint32_t>(1, s->n_leaves));
+    if (s->n_nodes) HIP_TRY(hipMemcpy(nodes.data(), s->d.nodes, sizeof(Bvh4Node) * size_t(s->n_nodes), hipMemcpyDeviceToHost));
+    if (s->n_leaves) HIP_TRY(hipMemcpy(leaves.data(), s->d.leaves, sizeof(LeafBlock) * size_t(s->n_leaves), hipMemcpyDeviceToHost));
+    std::vector<uint32_t> roots = s->model_roots;
+    BvhBuildResult r;
+    r.nodes = nodes.data(); r.n_nodes = s->n_nodes; r.leaves = leaves.data(); r.n_leaves = s->n_leaves;
+    r.model_root = roots.data(); r.max_depth = s->bvh_depth; r.max_stack = s->bvh_stack;
+    bvh_walk_check(flat, r, out);
+    out->build_seconds = s->build_seconds;
     return RT_OK;
 }
 

@@ -68,3 +68,6 @@ struct BvhBuildResult {
 // worst-case traversal stack <= RT_QSTACK) into one shared node array. Returns 0 on success. Caller frees with bvh_free.
 int bvh_build(const rt_flat_scene* scene, BvhBuildResult* out);
 void bvh_free(BvhBuildResult* r);
+struct rt_bvh_check_result;
+// Walks a finished tree (host arrays) and fills `out` (everything but build_seconds); see rt_bvh_check.
+void bvh_walk_check(const rt_flat_scene* scene, const BvhBuildResult& r, rt_bvh_check_result* out);

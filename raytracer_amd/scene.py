@@ -356,12 +356,20 @@ def bvh_check(flat):
 class DeviceScene:
     """rt_scene on one GPU. Fails loudly when the HIP library or a GPU is missing."""
 
-    def __init__(self, flat, device=0):
+    def __init__(self, flat, device=0, bvh="host"):
+        """bvh = "host": the SAH builder (rt_scene_create); "device": rt_scene_create_ex with RT_SCENE_BVH_DEVICE."""
         self.lib = cabi.load()
         self.flat = flat
         self.device = device
         self.h = C.c_void_p()
-        cabi.check(self.lib, self.lib.rt_scene_create(C.byref(flat.c_struct()), device, C.byref(self.h)))
+        flags = {"host": 0, "device": cabi.RT_SCENE_BVH_DEVICE}[bvh]
+        cabi.check(self.lib, self.lib.rt_scene_create_ex(C.byref(flat.c_struct()), device, flags, C.byref(self.h)))
+
+    def bvh_check(self):
+        """rt_scene_bvh_check: the tree this scene holds in HBM, copied back and walked on the host."""
+        out = cabi.rt_bvh_check_result()
+        cabi.check(self.lib, self.lib.rt_scene_bvh_check(self.h, C.byref(self.flat.c_struct()), C.byref(out)))
+        return out
 
     def close(self):
         if self.h:
