@@ -163,6 +163,13 @@ int rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_params* par
                      uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
                      uint8_t* d_bgr_out, void* stream, rt_stats* stats);
 
+/* Waits for the scene's outstanding asynchronous frames and says whether they are good: RT_OK, or RT_ERR_OVERFLOW
+ * when one of them ran out of the pool that holds the child rays (a scene whose ray trees branch more than the
+ * workspace allows for; the synchronous calls re-run such passes in smaller pieces by themselves, an asynchronous
+ * call cannot). The pixels of that frame are then not valid; the scene has already switched to smaller passes, so
+ * the caller renders the frame again. No counterpart in the reference (its recursion needs no pool). */
+int rt_scene_status(rt_scene* scene);
+
 /* The scene's own stream (a hipStream_t): the one asynchronous calls use when `stream` is NULL. Callers that have
  * to order other work behind a frame (a collective, a copy) enqueue it there or wait for an event recorded there.
  * No counterpart in the reference (its render() is synchronous). */

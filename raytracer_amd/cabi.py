@@ -107,7 +107,7 @@ def u8ptr(a):
 EXPORTS = [
     "rt_scene_create", "rt_scene_create_ex", "rt_scene_destroy", "rt_render", "rt_render_device", "rt_render_tiles_device",
     "rt_tiles_owned", "rt_untile_device", "rt_cast_rays", "rt_intersect", "rt_occluded", "rt_trace",
-    "rt_scene_bvh_info", "rt_bvh_check", "rt_scene_bvh_check", "rt_scene_stream", "rt_set_count_work", "rt_get_work", "rt_last_error", "rt_version",
+    "rt_scene_bvh_info", "rt_bvh_check", "rt_scene_bvh_check", "rt_scene_status", "rt_scene_stream", "rt_set_count_work", "rt_get_work", "rt_last_error", "rt_version",
 ]
 
 HOST_EXPORTS = [
@@ -153,6 +153,7 @@ def load(path=None):
     lib.rt_scene_bvh_info.argtypes = [vp, C.POINTER(rt_bvh_info)]
     lib.rt_bvh_check.argtypes = [C.POINTER(rt_flat_scene), C.POINTER(rt_bvh_check_result)]
     lib.rt_scene_bvh_check.argtypes = [vp, C.POINTER(rt_flat_scene), C.POINTER(rt_bvh_check_result)]
+    lib.rt_scene_status.argtypes = [vp]
     lib.rt_scene_stream.argtypes = [vp]
     lib.rt_scene_stream.restype = C.c_void_p
     lib.rt_set_count_work.argtypes = [vp, C.c_int]

@@ -104,6 +104,11 @@ struct rt_scene {
     bool count_work = false;
     rt_work last_work[RT_N_KINDS]{};   // RT_K_* kernels
     int last_overflow = 0;
+    uint32_t* h_overflow = nullptr;      // pinned, written by k_resolve: an asynchronous frame ran out of pool
+    uint32_t shrink_log2 = 0;            // passes are cut 2^k times smaller than RT_PASS_SAMPLES: learned from overflows, sticky
+    hipStream_t last_stream = nullptr;   // stream of the most recent asynchronous frame
+    uint32_t last_spp = 1;
+    uint32_t ws_min_n0 = 0;              // the workspace is sized for at least this many samples per pass (grown after overflows)
 };
 
 static int free_scene(rt_scene* s) {
@@ -113,6 +118,7 @@ static int free_scene(rt_scene* s) {
     hipFree(s->node_a); hipFree(s->node_b); hipFree(s->rays); hipFree(s->hit_n); hipFree(s->hit_p); hipFree(s->queue_e); hipFree(s->queue_s); hipFree(s->d_counters); hipFree(s->d_aa); hipFree(s->d_frame);
     if (s->h_counters) hipHostFree(s->h_counters);
     if (s->h_hint) hipHostFree(s->h_hint);
+    if (s->h_overflow) hipHostFree(s->h_overflow);
     for (auto& g : s->graphs) hipGraphExecDestroy(g.exec);
     hipFree(s->d_fp);
     if (s->ev_begin) hipEventDestroy(s->ev_begin);
@@ -267,6 +273,7 @@ extern "C" int rt_scene_create_ex(const rt_flat_scene* sc, int device, uint32_t 
     if (hipMalloc(reinterpret_cast<void**>(&s->d_counters), sizeof(PassCounters) * RT_MAX_PASSES) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&s->h_counters), sizeof(PassCounters) * RT_MAX_PASSES) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&s->h_hint), sizeof(ShardCounters) * RT_SHARDS) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&s->h_overflow), 64) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&s->d_fp), sizeof(FrameParams)) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&s->d_aa), sizeof(float) * 2 * (RT_MAX_AA_POINTS + 1)) != hipSuccess ||
         hipEventCreate(&s->ev_begin) != hipSuccess || hipEventCreate(&s->ev_end) != hipSuccess) {
@@ -275,12 +282,28 @@ extern "C" int rt_scene_create_ex(const rt_flat_scene* sc, int device, uint32_t 
         return RT_ERR_DEVICE;
     }
     std::memset(s->h_hint, 0, sizeof(ShardCounters) * RT_SHARDS);
+    *s->h_overflow = 0;
     for (int i = 0; i < RT_MAX_LEVELS + 4; ++i) s->h_hint[0].level[i] = 0xFFFFFFFFu;   // unknown: assume large levels
     *out = s;
     return RT_OK;
 }
 
 extern "C" void rt_scene_destroy(rt_scene* s) { free_scene(s); }
+
+static void learn_from_overflow(rt_scene* s, uint32_t full_px);
+
+extern "C" int rt_scene_status(rt_scene* s) {
+    if (!s) { rt_set_error("null scene"); return RT_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(s->device));
+    if (s->last_stream) HIP_TRY(hipStreamSynchronize(s->last_stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    const bool over = *s->h_overflow != 0 || s->last_overflow == 1;
+    if (*s->h_overflow && s->last_overflow != 1) learn_from_overflow(s, std::max<uint32_t>(64u, RT_PASS_SAMPLES / std::max<uint32_t>(1u, s->last_spp)));   // not yet accounted for
+    *s->h_overflow = 0;
+    s->last_overflow = 0;
+    if (over) { rt_set_error("an asynchronous frame ran out of ray pool; the scene now uses smaller passes: render it again"); return RT_ERR_OVERFLOW; }
+    return RT_OK;
+}
 
 extern "C" void* rt_scene_stream(const rt_scene* s) { return s ? static_cast<void*>(s->stream) : nullptr; }
 
@@ -478,6 +501,9 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
         A.sample0 = (px0 + done) * spp;
         A.sc = pc->sc;
         A.cancelled = pc->cancel;
+        A.host_overflow = s->h_overflow;
+        // small passes: smaller level-0 chunks, so that all shards (sub-pools) get their share of the entries
+        while (A.chunk_log2 > 0 && (A.n0 >> (6u + A.chunk_log2)) < RT_SHARDS) --A.chunk_log2;
         A.overflow = &pc->overflow;
         A.shadow_count = pc->shadow;
         A.work = &pc->work[0][0][0];
@@ -592,6 +618,13 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
     return RT_OK;
 }
 
+// An asynchronous frame overflowed: the next ones get 4x the room per sample, by smaller passes while those can shrink,
+// then by a larger pool.
+static void learn_from_overflow(rt_scene* s, uint32_t full_px) {
+    if ((full_px >> s->shrink_log2) > 64u && s->shrink_log2 < 16) s->shrink_log2 = std::min(16u, s->shrink_log2 + 2u);
+    else s->ws_min_n0 = uint32_t(std::min<uint64_t>(RT_PASS_SAMPLES, std::max<uint64_t>(uint64_t(s->ws_n0) * 8u, 65536u)));
+}
+
 static int render_frame(rt_scene* s, const rt_camera* cam, const rt_params* prm, const PixelMap& pm, uint8_t* d_out,
                         hipStream_t st, rt_stats* stats, bool sync) {
     HIP_TRY(hipSetDevice(s->device));
@@ -599,9 +632,13 @@ static int render_frame(rt_scene* s, const rt_camera* cam, const rt_params* prm,
     const uint64_t total_px = uint64_t(pm.n_owned) * pm.tile_w * pm.tile_h;
     if (stats) std::memset(stats, 0, sizeof *stats);
     if (total_px == 0) return RT_OK;
-    uint32_t pass_px = uint32_t(std::min<uint64_t>(total_px, std::max<uint32_t>(64u, RT_PASS_SAMPLES / spp)));
+    // The workspace is sized for the full pass; a scene whose ray trees outgrow the pool (learned from overflows, below
+    // and in rt_scene_status) runs smaller passes in the same workspace: 2^k times the room per sample.
+    const uint32_t full_px = std::max<uint32_t>(64u, RT_PASS_SAMPLES / spp);
+    if (*s->h_overflow && s->last_overflow == -1) { s->last_overflow = 1; learn_from_overflow(s, full_px); }
+    uint32_t pass_px = uint32_t(std::min<uint64_t>(total_px, std::max<uint32_t>(64u, full_px >> s->shrink_log2)));
     pass_px = (pass_px + 63u) & ~63u;
-    int rc = ensure_workspace(s, pass_px * spp);
+    int rc = ensure_workspace(s, std::max(((uint32_t(std::min<uint64_t>(total_px, full_px)) + 63u) & ~63u) * spp, s->ws_min_n0));
     if (rc != RT_OK) return rc;
 
     FrameJob J{};
@@ -644,7 +681,9 @@ static int render_frame(rt_scene* s, const rt_camera* cam, const rt_params* prm,
         // become two). Measured on ROCm 7.2 / MI355X the replay is slower than the direct launches (bunny_1080p,
         // two frames in flight: 1.25 vs 0.82 ms/frame; an eighth of the tiles: 0.46 vs 0.24 ms): the captured
         // multi-stream schedule loses its overlap. So the graph path is opt-in (RT_USE_GRAPH=1) and off by default.
-        s->last_overflow = -1;
+        if (s->last_overflow != 1) s->last_overflow = -1;      // unknown until rt_scene_status (1 stays until it is read)
+        s->last_stream = st;
+        s->last_spp = spp;
         static const bool no_graph = std::getenv("RT_USE_GRAPH") == nullptr;
         rt_scene::GraphKey key;
         std::memset(&key, 0, sizeof key);
@@ -709,16 +748,43 @@ static int render_frame(rt_scene* s, const rt_camera* cam, const rt_params* prm,
             const PassRec r = recs[i];
             if (!s->h_counters[r.slot].overflow) { final_recs.push_back(r); continue; }
             ++retries;
-            if (r.npx <= 64) { rt_set_error("bounce queue overflow on a 64-pixel pass"); return RT_ERR_OVERFLOW; }
-            uint32_t half = ((r.npx / 2) + 63u) & ~63u;
-            if (J.n_pass_used + 2 > RT_MAX_PASSES) { rt_set_error("out of pass slots while retrying"); return RT_ERR_OVERFLOW; }
-            HIP_TRY(hipMemsetAsync(s->d_counters + J.n_pass_used, 0, sizeof(PassCounters) * 2, st));
-            rc = enqueue_passes(J, r.px0, r.npx, half, recs);
+            // how much more room than it had does the fullest sub-pool need, as far as the pass got? (The counters hold
+            // the ATTEMPTED appends; levels behind the overflow are missing, so this is a lower bound.)
+            uint64_t worst = 0;
+            for (uint32_t k = 0; k < RT_SHARDS; ++k) {
+                uint64_t n = 0;
+                for (int lv = 1; lv < RT_MAX_LEVELS; ++lv) n += s->h_counters[r.slot].sc[k].level[lv];
+                worst = std::max(worst, n);
+            }
+            uint32_t cut = 2;
+            while (uint64_t(cut) * s->sub_cap < worst * 2 && cut < 1024u) cut *= 2;
+            uint32_t part = std::max<uint32_t>(64u, ((r.npx / cut) + 63u) & ~63u);
+            if (part >= r.npx) {
+                // a 64-pixel pass cannot be cut: the pool itself has to grow (as if for a larger frame), up to the size a
+                // full pass gets. Everything enqueued so far must be done before the old arrays go.
+                if (s->ws_n0 >= RT_PASS_SAMPLES) { rt_set_error("bounce queue overflow on a 64-pixel pass with the largest pool"); return RT_ERR_OVERFLOW; }
+                HIP_TRY(hipStreamSynchronize(st));
+                s->ws_min_n0 = uint32_t(std::min<uint64_t>(RT_PASS_SAMPLES, std::max<uint64_t>(uint64_t(s->ws_n0) * 8u, 65536u)));
+                if ((rc = ensure_workspace(s, s->ws_min_n0)) != RT_OK) return rc;
+                LevelArgs& Bn = J.base;
+                Bn.sub_cap = s->sub_cap;
+                Bn.rays = s->rays; Bn.node_a = s->node_a; Bn.node_b = s->node_b; Bn.hit_n = s->hit_n; Bn.hit_p = s->hit_p; Bn.queue_e = s->queue_e; Bn.queue_s = s->queue_s;
+                part = r.npx;
+            }
+            const uint32_t n_new = (r.npx + part - 1) / part;
+            if (J.n_pass_used + n_new > RT_MAX_PASSES) { rt_set_error("out of pass slots while retrying"); return RT_ERR_OVERFLOW; }
+            HIP_TRY(hipMemsetAsync(s->d_counters + J.n_pass_used, 0, sizeof(PassCounters) * n_new, st));
+            rc = enqueue_passes(J, r.px0, r.npx, part, recs);
             if (rc != RT_OK) return rc;
+            // remember it: the next frames of this scene start with passes that fit
+            uint32_t lg = 0;
+            while ((full_px >> lg) > part && (full_px >> lg) > 64u && lg < 16) ++lg;
+            s->shrink_log2 = std::max(s->shrink_log2, lg);
         }
         checked = upto;
     }
     s->last_overflow = 0;
+    *s->h_overflow = 0;
     if (stats) {
         HIP_TRY(hipEventRecord(s->ev_end, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -940,6 +1006,8 @@ static int trace_chunk(rt_scene* s, const rt_params* prm, const float* d_rays, u
     A.rays = s->rays;
     A.sub_cap = s->sub_cap;
     A.chunk_log2 = RT_SHARD_CHUNK_LOG2;
+    while (A.chunk_log2 > 0 && (A.n0 >> (6u + A.chunk_log2)) < RT_SHARDS) --A.chunk_log2;
+    A.host_overflow = nullptr;
     FrameParams fp;
     std::memset(&fp, 0, sizeof fp);
     std::memcpy(fp.background, prm->background, sizeof fp.background);

@@ -1153,6 +1153,8 @@ __global__ __launch_bounds__(256) void k_fold(DScene S, LevelArgs A) {
 __global__ __launch_bounds__(256) void k_resolve(DScene S, LevelArgs A, uint8_t* __restrict__ out) {
     const uint32_t npix = A.n0 / A.spp;
     const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+    if (p == 0 && A.host_overflow && *A.overflow)       // tell the host without a copy: the pass ran out of pool
+        __hip_atomic_store(A.host_overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (p >= npix) return;
     uint32_t x, y; uint64_t off; bool inb;
     const bool valid = map_pixel(A.pm, A.sample0 / A.spp + p, x, y, off, inb);

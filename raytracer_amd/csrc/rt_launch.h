@@ -88,6 +88,7 @@ struct LevelArgs {
     ShardCounters* sc;           // [RT_SHARDS]
     uint32_t* cancelled;         // [RT_MAX_LEVELS+1] per level: speculative children whose parent took the red exit
     uint32_t* overflow;          // set to 1 if a child did not fit
+    uint32_t* host_overflow;     // pinned host word: k_resolve raises it when the pass overflowed (asynchronous frames)
     unsigned long long* shadow_count;   // [RT_STAT_SHARDS], indexed by workgroup
     unsigned long long* work;    // [RT_WORK_SHARDS][RT_N_KINDS][12] traversal work counters (COUNT builds only)
     float4* rays;                // 2 per pool entry >= n0: origin, direction

@@ -436,6 +436,10 @@ class DeviceScene:
         cabi.check(self.lib, self.lib.rt_scene_bvh_info(self.h, C.byref(info)))
         return info
 
+    def status(self):
+        """rt_scene_status: wait for the asynchronous frames; raises RtError (RT_ERR_OVERFLOW) if one ran out of pool."""
+        cabi.check(self.lib, self.lib.rt_scene_status(self.h))
+
     def stream(self):
         """The scene's own hipStream_t (integer handle), used by asynchronous calls when no stream is passed."""
         return self.lib.rt_scene_stream(self.h)

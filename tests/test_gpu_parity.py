@@ -201,3 +201,61 @@ def test_nan_normal_red_exit(oracle_mod):
     f2, s2 = oracle_mod.Oracle(fs).render(cam, p)
     assert np.array_equal(f1, f2)
     assert s1.trace_calls == s2.trace_calls and s1.shadow_rays == s2.shadow_rays
+
+
+def hall_of_mirrors():
+    """Everything bounces: two reflective + refractive spheres between mirror walls. The ray tree of a sample has
+    hundreds of nodes, far more than the 6 the pool is sized for."""
+    fs = wl.FlatScene()
+    mats = wl.yaml_materials()
+    fs.add_sphere((-1.2, 0.0, -6.0), 1.0, mats["glass2"])
+    fs.add_sphere((1.2, 0.3, -7.0), 1.0, mats["glass2"])
+    for nrm, d in [((0, 0, 1), 12.0), ((1, 0, 0), 4.0), ((-1, 0, 0), 4.0), ((0, 1, 0), 4.0), ((0, -1, 0), 4.0)]:
+        fs.add_plane(nrm, d, mats["mirror"])
+    wl.add_yaml_lights(fs)
+    return fs
+
+
+def test_pool_overflow_is_rerun_in_smaller_passes(oracle_mod):
+    """Synchronous calls re-run a pass whose ray trees outgrow the pool in smaller pieces; the frame and the ray counts
+    still equal the reference's recursion."""
+    O = oracle_mod
+    fs = hall_of_mirrors()
+    cam = reference_camera(96, 72)
+    p = Params(max_depth=8)
+    dev = DeviceScene(fs)
+    got, st1 = dev.render(cam, p)
+    want, st2 = O.Oracle(fs).render(cam, p)
+    within1, equal, worst = frame_stats(got, want)
+    print(f"hall of mirrors: {st1.trace_calls} trace calls for {96 * 72} samples, passes {st1.passes}, retries {st1.retries}, "
+          f"within 1 LSB {within1:.6f}")
+    assert st1.retries > 0 and st1.passes > 1
+    assert st1.trace_calls == st2.trace_calls and st1.shadow_rays == st2.shadow_rays
+    assert within1 >= 0.999
+    # the scene remembers: the same frame again needs no retry
+    again, st3 = dev.render(cam, p)
+    assert st3.retries == 0 and np.array_equal(again, got)
+
+
+def test_async_overflow_is_reported_then_fits():
+    """An asynchronous frame cannot re-run passes; rt_scene_status reports the overflow, the scene shrinks its passes
+    and the frame rendered again equals the synchronous one."""
+    import torch
+    from raytracer_amd.cabi import RtError
+    fs = hall_of_mirrors()
+    cam = reference_camera(96, 72)
+    p = Params(max_depth=8)
+    want, _ = DeviceScene(fs).render(cam, p)
+    dev = DeviceScene(fs)
+    frame = torch.zeros((72, 96, 3), dtype=torch.uint8, device="cuda")
+    ok = False
+    for attempt in range(12):
+        dev.render_device(cam, p, frame.data_ptr())
+        try:
+            dev.status()
+            ok = True
+            break
+        except RtError as e:
+            assert "pool" in str(e)
+    assert ok and attempt >= 1
+    assert np.array_equal(frame.cpu().numpy(), want)
