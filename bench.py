@@ -228,6 +228,8 @@ def main():
                        "scene_build_s": round(build_s, 3), "bvh": args.bvh,
                        "bvh_build_s": round(dev.bvh_info().build_seconds, 4)},
         }
+        for sl in slots:        # no asynchronous frame ran out of ray pool (raises otherwise)
+            sl.dev.status()
         used = slots[:min(len(slots), args.steps + args.warmup)]
         identical = all(bool(torch.equal(sl.frame, ref_frame)) for sl in used)
         out["frame_identical_to_1gpu"] = identical

@@ -22,6 +22,7 @@
 // contraction; the x86 reference build has none), correctly rounded f32 divide/sqrt (hipcc default), and double
 // exactly where the reference's overload resolution computes in double (sphere roots, pow, camera tan product).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <float.h>
 #include <stdint.h>
 
@@ -1122,9 +1123,11 @@ __device__ __forceinline__ V3 node_color(const DScene& S, const float4* __restri
     return finish_color(mk(a.x, a.y, a.z), m, a.w, refl, refr);
 }
 
-// Frame parameters by value -> device memory (one tiny launch per frame; see FrameParams).
-__global__ void k_set_frame_params(FrameParams p, FrameParams* dst) {
+// Frame parameters by value -> device memory, and the frame's pass counters cleared (one small launch per frame
+// instead of a launch and a memset; see FrameParams).
+__global__ __launch_bounds__(256) void k_set_frame_params(FrameParams p, FrameParams* dst, uint4* clear, uint32_t n_clear16) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *dst = p;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_clear16; i += gridDim.x * 256) clear[i] = make_uint4(0, 0, 0, 0);
 }
 
 // Fold of one level (>= 1): finishes every node whose children were traced one level deeper.
@@ -1312,8 +1315,10 @@ void launch_shade(int form, bool count, const DScene& S, const LevelArgs& A, uin
     if (S.generic_pow) { if (count) launch_shade_t<true, true>(form, S, A, g, b, st); else launch_shade_t<false, true>(form, S, A, g, b, st); }
     else { if (count) launch_shade_t<true, false>(form, S, A, g, b, st); else launch_shade_t<false, false>(form, S, A, g, b, st); }
 }
-void launch_set_frame_params(const FrameParams& p, FrameParams* dst, hipStream_t st) {
-    hipLaunchKernelGGL(k_set_frame_params, dim3(1), dim3(64), 0, st, p, dst);
+void launch_set_frame_params(const FrameParams& p, FrameParams* dst, void* clear, size_t clear_bytes, hipStream_t st) {
+    const uint32_t n16 = uint32_t(clear_bytes / 16);
+    const uint32_t grid = n16 ? std::min<uint32_t>((n16 + 255u) / 256u, 1024u) : 1u;
+    hipLaunchKernelGGL(k_set_frame_params, dim3(grid), dim3(256), 0, st, p, dst, static_cast<uint4*>(clear), n16);
 }
 void launch_fold(const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st) {
     hipLaunchKernelGGL(k_fold, dim3(grid), dim3(256), 0, st, S, A);
