@@ -54,7 +54,11 @@ struct PassCounters {                 // one per pass, zeroed by one memset per 
 };
 
 #define RT_MAX_PASSES 1024
-#define RT_PASS_SAMPLES (4u << 20)    // level-0 samples per pass
+static uint32_t pass_samples() {      // level-0 samples per pass (RT_PASS_LOG2 in the environment: experiments)
+    static const uint32_t n = [] { const char* e = std::getenv("RT_PASS_LOG2"); const int k = e ? std::atoi(e) : 23; return 1u << std::max(12, std::min(26, k)); }();
+    return n;
+}
+#define RT_PASS_SAMPLES pass_samples()
 #define RT_POOL_FACTOR 6u             // node pool = 6x the pass size when materials bounce (level 0 + 5x for deeper levels)
 #define RT_MAX_TIMED 2048
 #define RT_MAX_GRAPHS 8
