@@ -163,6 +163,21 @@ int rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_params* par
                      uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
                      uint8_t* d_bgr_out, void* stream, rt_stats* stats);
 
+/* A BATCH of frames in one call: n_frames (1..16) frames of the same size, scene and params that differ only in
+ * their cameras (an animation's consecutive frames, or the steps of a benchmark). Frame b is written
+ * frame_stride_bytes * b behind d_bgr_out. Every launch then works on n_frames times as many rays: a small frame - or
+ * one GPU's share of a frame - leaves most of the chip idle in its deep bounce levels and is bound by the host's
+ * launch rate; a batch costs one frame's launches. Results are those of n_frames single calls, byte for byte.
+ * Replaces: a loop of render() calls (reference src/raytracer.cpp:422-463). */
+int rt_render_batch_device(rt_scene* scene, const rt_camera* cams, uint32_t n_frames, const rt_params* params,
+                           uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
+                           uint8_t* d_bgr_out, uint64_t frame_stride_bytes, void* stream, rt_stats* stats);
+/* The tile form (see rt_render_tiles_device): frame b's tile-major buffer starts frame_stride_bytes * b behind
+ * d_tiles_out. */
+int rt_render_tiles_batch_device(rt_scene* scene, const rt_camera* cams, uint32_t n_frames, const rt_params* params,
+                                 uint32_t tile_w, uint32_t tile_h, uint32_t part, uint32_t n_parts,
+                                 uint8_t* d_tiles_out, uint64_t frame_stride_bytes, void* stream, rt_stats* stats);
+
 /* Waits for the scene's outstanding asynchronous frames and says whether they are good: RT_OK, or RT_ERR_OVERFLOW
  * when one of them ran out of the pool that holds the child rays (a scene whose ray trees branch more than the
  * workspace allows for; the synchronous calls re-run such passes in smaller pieces by themselves, an asynchronous

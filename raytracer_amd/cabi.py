@@ -106,6 +106,7 @@ def u8ptr(a):
 # Every symbol include/raytracer_amd.h declares; tests check the library exports all of them.
 EXPORTS = [
     "rt_scene_create", "rt_scene_create_ex", "rt_scene_destroy", "rt_render", "rt_render_device", "rt_render_tiles_device",
+    "rt_render_batch_device", "rt_render_tiles_batch_device",
     "rt_tiles_owned", "rt_untile_device", "rt_cast_rays", "rt_intersect", "rt_occluded", "rt_trace",
     "rt_scene_bvh_info", "rt_bvh_check", "rt_scene_bvh_check", "rt_scene_status", "rt_scene_stream", "rt_set_count_work", "rt_get_work", "rt_last_error", "rt_version",
 ]
@@ -142,6 +143,10 @@ def load(path=None):
                                      vp, vp, C.POINTER(rt_stats)]
     lib.rt_render_tiles_device.argtypes = [vp, C.POINTER(rt_camera), C.POINTER(rt_params), u32, u32, u32,
                                            u32, vp, vp, C.POINTER(rt_stats)]
+    lib.rt_render_batch_device.argtypes = [vp, C.POINTER(rt_camera), u32, C.POINTER(rt_params), u32, u32, u32, u32,
+                                           vp, C.c_uint64, vp, C.POINTER(rt_stats)]
+    lib.rt_render_tiles_batch_device.argtypes = [vp, C.POINTER(rt_camera), u32, C.POINTER(rt_params), u32, u32, u32,
+                                                 u32, vp, C.c_uint64, vp, C.POINTER(rt_stats)]
     lib.rt_tiles_owned.argtypes = [u32] * 6
     lib.rt_tiles_owned.restype = u32
     lib.rt_untile_device.argtypes = [C.c_int, u32, u32, u32, u32, u32, u32, vp, vp, vp]

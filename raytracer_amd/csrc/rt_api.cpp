@@ -278,7 +278,7 @@ extern "C" int rt_scene_create_ex(const rt_flat_scene* sc, int device, uint32_t 
         hipHostMalloc(reinterpret_cast<void**>(&s->h_counters), sizeof(PassCounters) * RT_MAX_PASSES) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&s->h_hint), sizeof(ShardCounters) * RT_SHARDS) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&s->h_overflow), 64) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&s->d_fp), sizeof(FrameParams)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&s->d_fp), sizeof(FrameParams) * RT_MAX_BATCH) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&s->d_aa), sizeof(float) * 2 * (RT_MAX_AA_POINTS + 1)) != hipSuccess ||
         hipEventCreate(&s->ev_begin) != hipSuccess || hipEventCreate(&s->ev_end) != hipSuccess) {
         rt_set_error("workspace allocation failed: %s", hipGetErrorString(hipGetLastError()));
@@ -634,13 +634,17 @@ static void learn_from_overflow(rt_scene* s, uint32_t full_px) {
     else s->ws_min_n0 = uint32_t(std::min<uint64_t>(RT_PASS_SAMPLES, std::max<uint64_t>(uint64_t(s->ws_n0) * 8u, 65536u)));
 }
 
-static int render_frame(rt_scene* s, const rt_camera* cam, const rt_params* prm, const PixelMap& pm, uint8_t* d_out,
-                        hipStream_t st, rt_stats* stats, bool sync) {
+// Renders n_frames frames that differ only in their cameras (cam[0..n_frames)) as ONE sample range: frame b's pixels
+// follow frame b-1's, frame b's output starts b * out_stride bytes behind d_out.
+static int render_frame(rt_scene* s, const rt_camera* cam, uint32_t n_frames, const rt_params* prm, const PixelMap& pm,
+                        uint8_t* d_out, uint64_t out_stride, hipStream_t st, rt_stats* stats, bool sync) {
     HIP_TRY(hipSetDevice(s->device));
     const uint32_t spp = 1 + prm->n_aa;
-    const uint64_t total_px = uint64_t(pm.n_owned) * pm.tile_w * pm.tile_h;
+    const uint64_t frame_px = uint64_t(pm.n_owned) * pm.tile_w * pm.tile_h;
+    const uint64_t total_px = frame_px * n_frames;
     if (stats) std::memset(stats, 0, sizeof *stats);
     if (total_px == 0) return RT_OK;
+    if (n_frames > 1 && frame_px * spp > 0xFFFFFFC0ull) { rt_set_error("frames of a batch are limited to 2^32 samples each"); return RT_ERR_LIMIT; }
     // The workspace is sized for the full pass; a scene whose ray trees outgrow the pool (learned from overflows, below
     // and in rt_scene_status) runs smaller passes in the same workspace: 2^k times the room per sample.
     const uint32_t full_px = std::max<uint32_t>(64u, RT_PASS_SAMPLES / spp);
@@ -664,6 +668,8 @@ static int render_frame(rt_scene* s, const rt_camera* cam, const rt_params* prm,
     B.aa = s->d_aa;
     B.fp = s->d_fp;
     B.pm = pm;
+    B.frame_samples = n_frames > 1 ? uint32_t(frame_px * spp) : 0u;
+    B.out_stride = out_stride;
     for (int lv = 0; lv <= prm->max_depth; ++lv)
         if (expect_large(s, lv, lv)) J.large_mask |= 1u << lv;
 
@@ -676,13 +682,15 @@ static int render_frame(rt_scene* s, const rt_camera* cam, const rt_params* prm,
         s->aa_cache.assign(prm->aa_xy, prm->aa_xy + 2 * prm->n_aa);
         HIP_TRY(hipMemcpyAsync(s->d_aa, prm->aa_xy, sizeof(float) * 2 * prm->n_aa, hipMemcpyHostToDevice, st));
     }
-    FrameParams fp;
+    FrameParamsBatch fp;
     std::memset(&fp, 0, sizeof fp);
-    std::memcpy(fp.background, prm->background, sizeof fp.background);
-    fp.cam = to_dcamera(cam);
+    for (uint32_t b = 0; b < n_frames; ++b) {
+        std::memcpy(fp.f[b].background, prm->background, sizeof fp.f[b].background);
+        fp.f[b].cam = to_dcamera(cam + b);
+    }
     const size_t counter_bytes = sizeof(PassCounters) * std::min<uint64_t>(RT_MAX_PASSES, n_pass * 2 + 16);
     static_assert(sizeof(PassCounters) % 16 == 0, "counters are cleared 16 bytes at a time");
-    launch_set_frame_params(fp, s->d_fp, s->d_counters, counter_bytes, st);      // also clears the frame's pass counters
+    launch_set_frame_params(fp, n_frames, s->d_fp, s->d_counters, counter_bytes, st);      // also clears the frame's pass counters
     std::vector<PassRec> recs;
     if (!sync) {
         // Asynchronous call: overflow (if any) is left in the counters. The launches of the frame depend on nothing
@@ -844,16 +852,34 @@ static int check_rect(const rt_camera* cam, uint32_t x0, uint32_t y0, uint32_t w
     return RT_OK;
 }
 
+// every camera of a batch: valid, and the same image size as the first
+static int check_batch(const rt_camera* cams, uint32_t n_frames, const rt_params* prm) {
+    if (!cams || n_frames == 0 || n_frames > RT_MAX_BATCH) { rt_set_error("a batch holds 1..%d frames", RT_MAX_BATCH); return RT_ERR_INVALID; }
+    for (uint32_t b = 0; b < n_frames; ++b) {
+        const int rc = check_params(cams + b, prm);
+        if (rc != RT_OK) return rc;
+        if (cams[b].imWidth != cams[0].imWidth || cams[b].imHeight != cams[0].imHeight) { rt_set_error("the frames of a batch must have one image size"); return RT_ERR_INVALID; }
+    }
+    return RT_OK;
+}
+
+extern "C" int rt_render_batch_device(rt_scene* s, const rt_camera* cams, uint32_t n_frames, const rt_params* prm, uint32_t x0,
+                                      uint32_t y0, uint32_t w, uint32_t h, uint8_t* d_bgr, uint64_t frame_stride_bytes,
+                                      void* stream, rt_stats* stats) {
+    if (!s || !d_bgr) { rt_set_error("null argument"); return RT_ERR_INVALID; }
+    int rc = check_batch(cams, n_frames, prm);
+    if (rc != RT_OK) return rc;
+    if ((rc = check_rect(cams, x0, y0, w, h)) != RT_OK) return rc;
+    if (n_frames > 1 && frame_stride_bytes < uint64_t(cams->imWidth) * cams->imHeight * 3u) { rt_set_error("frame stride smaller than a frame"); return RT_ERR_INVALID; }
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : s->stream;
+    rc = render_frame(s, cams, n_frames, prm, rect_map(cams, x0, y0, w, h), d_bgr, frame_stride_bytes, st, stats, stats != nullptr);
+    if (rc == RT_OK) finish_stats(stats, uint64_t(w) * h * n_frames, 1 + prm->n_aa);
+    return rc;
+}
+
 extern "C" int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_params* prm, uint32_t x0, uint32_t y0,
                                 uint32_t w, uint32_t h, uint8_t* d_bgr, void* stream, rt_stats* stats) {
-    if (!s || !d_bgr) { rt_set_error("null argument"); return RT_ERR_INVALID; }
-    int rc = check_params(cam, prm);
-    if (rc != RT_OK) return rc;
-    if ((rc = check_rect(cam, x0, y0, w, h)) != RT_OK) return rc;
-    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : s->stream;
-    rc = render_frame(s, cam, prm, rect_map(cam, x0, y0, w, h), d_bgr, st, stats, stats != nullptr);
-    if (rc == RT_OK) finish_stats(stats, uint64_t(w) * h, 1 + prm->n_aa);
-    return rc;
+    return rt_render_batch_device(s, cam, 1, prm, x0, y0, w, h, d_bgr, 0, stream, stats);
 }
 
 extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_params* prm, uint32_t x0, uint32_t y0, uint32_t w,
@@ -871,7 +897,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_params* prm
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_frame), need));
         s->frame_bytes = need;
     }
-    rc = render_frame(s, cam, prm, rect_map(cam, x0, y0, w, h), s->d_frame, s->stream, stats, true);
+    rc = render_frame(s, cam, 1, prm, rect_map(cam, x0, y0, w, h), s->d_frame, 0, s->stream, stats, true);
     if (rc != RT_OK) return rc;
     finish_stats(stats, uint64_t(w) * h, 1 + prm->n_aa);
     const size_t pitch = size_t(cam->imWidth) * 3, off = (size_t(y0) * cam->imWidth + x0) * 3;
@@ -891,8 +917,14 @@ extern "C" uint32_t rt_tiles_owned(uint32_t W, uint32_t H, uint32_t tw, uint32_t
 
 extern "C" int rt_render_tiles_device(rt_scene* s, const rt_camera* cam, const rt_params* prm, uint32_t tw, uint32_t th,
                                       uint32_t part, uint32_t n_parts, uint8_t* d_tiles, void* stream, rt_stats* stats) {
+    return rt_render_tiles_batch_device(s, cam, 1, prm, tw, th, part, n_parts, d_tiles, 0, stream, stats);
+}
+
+extern "C" int rt_render_tiles_batch_device(rt_scene* s, const rt_camera* cam, uint32_t n_frames, const rt_params* prm,
+                                            uint32_t tw, uint32_t th, uint32_t part, uint32_t n_parts, uint8_t* d_tiles,
+                                            uint64_t frame_stride_bytes, void* stream, rt_stats* stats) {
     if (!s || !d_tiles) { rt_set_error("null argument"); return RT_ERR_INVALID; }
-    int rc = check_params(cam, prm);
+    int rc = check_batch(cam, n_frames, prm);
     if (rc != RT_OK) return rc;
     if (!tw || !th || (tw & 7u) || (th & 7u)) { rt_set_error("tile size must be a positive multiple of 8"); return RT_ERR_INVALID; }
     if (!n_parts || part >= n_parts) { rt_set_error("part %u / n_parts %u invalid", part, n_parts); return RT_ERR_INVALID; }
@@ -904,7 +936,8 @@ extern "C" int rt_render_tiles_device(rt_scene* s, const rt_camera* cam, const r
     pm.n_owned = rt_tiles_owned(cam->imWidth, cam->imHeight, tw, th, part, n_parts);
     pm.tiled_out = 1; pm.stride_px = 0;
     hipStream_t st = stream ? static_cast<hipStream_t>(stream) : s->stream;
-    rc = render_frame(s, cam, prm, pm, d_tiles, st, stats, stats != nullptr);
+    if (n_frames > 1 && frame_stride_bytes < uint64_t(pm.n_owned) * tw * th * 3u) { rt_set_error("frame stride smaller than a part's tiles"); return RT_ERR_INVALID; }
+    rc = render_frame(s, cam, n_frames, prm, pm, d_tiles, frame_stride_bytes, st, stats, stats != nullptr);
     if (rc == RT_OK && stats) {
         // valid pixels of the owned tiles
         uint64_t valid = 0;
@@ -913,7 +946,7 @@ extern "C" int rt_render_tiles_device(rt_scene* s, const rt_camera* cam, const r
             const uint32_t vw = std::min(tw, cam->imWidth - tx * tw), vh = std::min(th, cam->imHeight - ty * th);
             valid += uint64_t(vw) * vh;
         }
-        finish_stats(stats, valid, 1 + prm->n_aa);
+        finish_stats(stats, valid * n_frames, 1 + prm->n_aa);
     }
     return rc;
 }
@@ -1014,10 +1047,10 @@ static int trace_chunk(rt_scene* s, const rt_params* prm, const float* d_rays, u
     A.chunk_log2 = RT_SHARD_CHUNK_LOG2;
     while (A.chunk_log2 > 0 && (A.n0 >> (6u + A.chunk_log2)) < RT_SHARDS) --A.chunk_log2;
     A.host_overflow = nullptr;
-    FrameParams fp;
+    FrameParamsBatch fp;
     std::memset(&fp, 0, sizeof fp);
-    std::memcpy(fp.background, prm->background, sizeof fp.background);
-    launch_set_frame_params(fp, s->d_fp, s->d_counters, sizeof(PassCounters), st);
+    std::memcpy(fp.f[0].background, prm->background, sizeof fp.f[0].background);
+    launch_set_frame_params(fp, 1, s->d_fp, s->d_counters, sizeof(PassCounters), st);
     A.fp = s->d_fp;
     const int levels = s->has_bounce ? A.max_depth : 0;
     const bool meshes = s->n_models > 0;

@@ -643,12 +643,17 @@ __device__ __forceinline__ void flush_work(unsigned long long* work, uint32_t ke
 template <int SRC>
 __device__ __forceinline__ bool fetch_ray(const LevelArgs& A, uint32_t begin, uint32_t i, Ray& ray) {
     if (SRC == 0) {
-        const uint64_t g = A.sample0 + (i - begin);
+        uint64_t g = A.sample0 + (i - begin);
+        uint32_t frame = 0;
+        if (A.frame_samples) {      // batch: the frame is the same for the whole 64-entry block (frame_samples % 64 == 0)
+            frame = (uint32_t)__builtin_amdgcn_readfirstlane((int)((A.sample0 + ((i - begin) & ~63u)) / A.frame_samples));
+            g -= (uint64_t)frame * A.frame_samples;
+        }
         uint32_t x, y; uint64_t off; bool inb;
         if (!map_pixel(A.pm, g / A.spp, x, y, off, inb)) return false;
         DCamera cam;                                                      // wave-uniform: scalar loads
         {
-            const RT_CONSTANT uint32_t* src = (const RT_CONSTANT uint32_t*)(const void*)(&A.fp->cam);
+            const RT_CONSTANT uint32_t* src = (const RT_CONSTANT uint32_t*)(const void*)(&A.fp[frame].cam);
             uint32_t* dst = reinterpret_cast<uint32_t*>(&cam);
 #pragma unroll
             for (int k = 0; k < (int)(sizeof(DCamera) / 4); ++k) dst[k] = src[k];
@@ -1125,8 +1130,8 @@ __device__ __forceinline__ V3 node_color(const DScene& S, const float4* __restri
 
 // Frame parameters by value -> device memory, and the frame's pass counters cleared (one small launch per frame
 // instead of a launch and a memset; see FrameParams).
-__global__ __launch_bounds__(256) void k_set_frame_params(FrameParams p, FrameParams* dst, uint4* clear, uint32_t n_clear16) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) *dst = p;
+__global__ __launch_bounds__(256) void k_set_frame_params(FrameParamsBatch p, uint32_t n_frames, FrameParams* dst, uint4* clear, uint32_t n_clear16) {
+    if (blockIdx.x == 0 && threadIdx.x < n_frames) dst[threadIdx.x] = p.f[threadIdx.x];
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_clear16; i += gridDim.x * 256) clear[i] = make_uint4(0, 0, 0, 0);
 }
 
@@ -1160,7 +1165,14 @@ __global__ __launch_bounds__(256) void k_resolve(DScene S, LevelArgs A, uint8_t*
         __hip_atomic_store(A.host_overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (p >= npix) return;
     uint32_t x, y; uint64_t off; bool inb;
-    const bool valid = map_pixel(A.pm, A.sample0 / A.spp + p, x, y, off, inb);
+    uint64_t q = A.sample0 / A.spp + p;
+    if (A.frame_samples) {          // batch: frame b's buffer starts b * out_stride bytes further
+        const uint32_t frame_px = A.frame_samples / A.spp;
+        const uint32_t b = (uint32_t)(q / frame_px);
+        q -= (uint64_t)b * frame_px;
+        out += (uint64_t)b * A.out_stride;
+    }
+    const bool valid = map_pixel(A.pm, q, x, y, off, inb);
     if (!valid) {
         if (A.pm.tiled_out && inb) { out[off] = 0; out[off + 1] = 0; out[off + 2] = 0; }
         return;
@@ -1315,10 +1327,10 @@ void launch_shade(int form, bool count, const DScene& S, const LevelArgs& A, uin
     if (S.generic_pow) { if (count) launch_shade_t<true, true>(form, S, A, g, b, st); else launch_shade_t<false, true>(form, S, A, g, b, st); }
     else { if (count) launch_shade_t<true, false>(form, S, A, g, b, st); else launch_shade_t<false, false>(form, S, A, g, b, st); }
 }
-void launch_set_frame_params(const FrameParams& p, FrameParams* dst, void* clear, size_t clear_bytes, hipStream_t st) {
+void launch_set_frame_params(const FrameParamsBatch& p, uint32_t n_frames, FrameParams* dst, void* clear, size_t clear_bytes, hipStream_t st) {
     const uint32_t n16 = uint32_t(clear_bytes / 16);
     const uint32_t grid = n16 ? std::min<uint32_t>((n16 + 255u) / 256u, 1024u) : 1u;
-    hipLaunchKernelGGL(k_set_frame_params, dim3(grid), dim3(256), 0, st, p, dst, static_cast<uint4*>(clear), n16);
+    hipLaunchKernelGGL(k_set_frame_params, dim3(grid), dim3(256), 0, st, p, n_frames, dst, static_cast<uint4*>(clear), n16);
 }
 void launch_fold(const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st) {
     hipLaunchKernelGGL(k_fold, dim3(grid), dim3(256), 0, st, S, A);

@@ -63,6 +63,11 @@ struct FrameParams {
     float pad;
     DCamera cam;
 };
+// A call may render a BATCH of frames that differ only in their cameras: the level-0 samples of frame b follow those
+// of frame b-1, so every launch works on n_frames times as many rays (a small frame, or one rank's share of a frame,
+// leaves most of the chip idle in its deep levels and is bound by the host's launch rate).
+#define RT_MAX_BATCH 16
+struct FrameParamsBatch { FrameParams f[RT_MAX_BATCH]; };
 
 #define RT_POW_MAX_INT 64
 #define RT_SHARDS 32u
@@ -102,7 +107,10 @@ struct LevelArgs {
     uint2* queue_s;              // same for k_shade_wide {pool entry, light << 16 | object}
     const float* aa;             // anti-aliasing pattern (device)
     const float* user_rays;      // SRC 2
-    const FrameParams* fp;       // camera + background of the frame (device)
+    const FrameParams* fp;       // [n_frames] camera + background of the frames (device); the background is the batch's
+    uint32_t frame_samples;      // batch: level-0 samples per frame (a multiple of 64); 0 = one frame
+    uint32_t pad3;
+    uint64_t out_stride;         // batch: bytes between the output buffers of consecutive frames
     uint32_t debug;              // timing experiments only (RT_DEBUG_SKIP)
     uint32_t chunk_log2;         // level-0 shard chunks (RT_SHARD_CHUNK_LOG2; RT_CHUNK_LOG2 in the environment for experiments)
     uint4* wave_log;             // diagnostics (COUNT builds, RT_WAVE_LOG): per workgroup {start, end, traversal ticks, batches}
@@ -119,7 +127,7 @@ struct UntileArgs {
 enum { RT_FORM_WIDE = 0, RT_FORM_QUAD_FRESH = 1, RT_FORM_QUAD_RESUME = 2, RT_FORM_QUAD_PARKED = 3 };
 void launch_extend(int src, int form, bool count, const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st);
 void launch_shade(int form, bool count, const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st);
-void launch_set_frame_params(const FrameParams& p, FrameParams* dst, void* clear, size_t clear_bytes, hipStream_t st);   // clear: 16-byte multiple
+void launch_set_frame_params(const FrameParamsBatch& p, uint32_t n_frames, FrameParams* dst, void* clear, size_t clear_bytes, hipStream_t st);   // clear: 16-byte multiple
 void launch_fold(const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st);
 void launch_resolve(const DScene& S, const LevelArgs& A, uint8_t* out, hipStream_t st);
 void launch_resolve_rgb(const DScene& S, const LevelArgs& A, float* rgb, hipStream_t st);

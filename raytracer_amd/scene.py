@@ -406,6 +406,22 @@ class DeviceScene:
                                                              C.c_void_p(stream or 0),
                                                              C.byref(stats) if stats is not None else None))
 
+    def render_batch_device(self, cams, params, d_ptr, frame_stride, rect=None, stream=None, stats=None):
+        """rt_render_batch_device: len(cams) frames (same size) in one call; frame b at d_ptr + b * frame_stride."""
+        arr = (rt_camera * len(cams))(*cams)
+        W, H = cams[0].imWidth, cams[0].imHeight
+        x0, y0, w, h = rect if rect is not None else (0, 0, W, H)
+        cabi.check(self.lib, self.lib.rt_render_batch_device(self.h, arr, len(cams), C.byref(params.c), x0, y0, w, h,
+                                                             C.c_void_p(d_ptr), int(frame_stride), C.c_void_p(stream or 0),
+                                                             C.byref(stats) if stats is not None else None))
+
+    def render_tiles_batch_device(self, cams, params, tile, part, n_parts, d_ptr, frame_stride, stream=None, stats=None):
+        arr = (rt_camera * len(cams))(*cams)
+        cabi.check(self.lib, self.lib.rt_render_tiles_batch_device(self.h, arr, len(cams), C.byref(params.c), tile[0], tile[1],
+                                                                   part, n_parts, C.c_void_p(d_ptr), int(frame_stride),
+                                                                   C.c_void_p(stream or 0),
+                                                                   C.byref(stats) if stats is not None else None))
+
     def intersect(self, rays, obj=-1):
         rays = cabi.as_f32(rays, (-1, 6))
         n = rays.shape[0]

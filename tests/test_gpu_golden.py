@@ -134,3 +134,54 @@ def test_full_size_properties():
     d = np.abs(a[y0:y0 + h, x0:x0 + w].astype(np.int16) - want[y0:y0 + h, x0:x0 + w].astype(np.int16)).max(axis=2)
     print(f"full-size strip: within 1 LSB {(d <= 1).mean():.6f}, equal {(d == 0).mean():.6f}")
     assert (d <= 1).mean() >= 0.999
+
+
+def test_batch_equals_single_frames():
+    """rt_render_batch_device / rt_render_tiles_batch_device: n frames with different cameras in one call are, byte for
+    byte, the n frames rendered one by one (and the ray counts add up)."""
+    import torch
+    from raytracer_amd.scene import make_camera
+    from raytracer_amd.cabi import rt_stats
+    fs = wl.scene_bunny(10, third="glass2")
+    dev = DeviceScene(fs)
+    W, H = 328, 200
+    cams = [make_camera(W, H, eye=(0.3 * k, 0.1 * k, 0.2 * k), at=(0.05 * k, 0, -1)) for k in range(5)]
+    p = Params(max_depth=6, aa=((0.5, 0.5),))
+    singles, rays = [], 0
+    for cam in cams:
+        f, st = dev.render(cam, p)
+        singles.append(f)
+        rays += st.trace_calls + st.shadow_rays
+    assert not np.array_equal(singles[0], singles[4])
+    stride = W * H * 3 + 256
+    buf = torch.zeros((5 * stride,), dtype=torch.uint8, device="cuda")
+    st = rt_stats()
+    dev.render_batch_device(cams, p, buf.data_ptr(), stride, stats=st)
+    got = buf.cpu().numpy()
+    for k in range(5):
+        assert np.array_equal(got[k * stride:k * stride + W * H * 3].reshape(H, W, 3), singles[k]), k
+    assert st.trace_calls + st.shadow_rays == rays
+    # asynchronous form, a rectangle of every frame
+    buf.zero_()
+    rect = (40, 16, 200, 120)
+    dev.render_batch_device(cams, p, buf.data_ptr(), stride, rect=rect)
+    dev.status()
+    got = buf.cpu().numpy()
+    x0, y0, w, h = rect
+    for k in range(5):
+        fr = got[k * stride:k * stride + W * H * 3].reshape(H, W, 3)
+        assert np.array_equal(fr[y0:y0 + h, x0:x0 + w], singles[k][y0:y0 + h, x0:x0 + w]), k
+        fr[y0:y0 + h, x0:x0 + w] = 0
+        assert not fr.any()
+    # tiles of 3 parts, 5 frames each, untiled per frame
+    tw = th = 32
+    parts = []
+    for part in range(3):
+        n = dev.lib.rt_tiles_owned(W, H, tw, th, part, 3)
+        tstride = n * tw * th * 3
+        t = torch.zeros((5 * tstride,), dtype=torch.uint8, device="cuda")
+        dev.render_tiles_batch_device(cams, p, (tw, th), part, 3, t.data_ptr(), tstride)
+        dev.status()
+        parts.append(t.cpu().numpy().reshape(5, tstride))
+    for k in range(5):
+        assert np.array_equal(tiling.untile([pp[k] for pp in parts], W, H, tw, th), singles[k]), k
