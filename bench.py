@@ -91,8 +91,8 @@ def cpu_baseline(fs, cam, params, dev, np):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default="bunny_1080p")
     ap.add_argument("--tile", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -101,6 +101,9 @@ def main():
                     help="rehearsal only: every rank uses GPU 0 (needs --backend gloo)")
     ap.add_argument("--frames-in-flight", type=int, default=2,
                     help="frames rendered concurrently (each in its own scene workspace and stream); 1 = one at a time")
+    ap.add_argument("--frames-per-batch", type=int, default=8,
+                    help="frames (steps) rendered per library call, rt_render_batch_device: every launch then carries "
+                         "that many frames' rays (1..16; 1 = one call per frame)")
     ap.add_argument("--bvh", default="host", choices=("host", "device"),
                     help="BVH builder: the host's SAH tree (default) or the GPU's linear BVH (RT_SCENE_BVH_DEVICE)")
     ap.add_argument("--watchdog", type=int, default=0, help="dump all Python stacks and exit after this many seconds")
@@ -139,9 +142,16 @@ def main():
     W, H = cam.imWidth, cam.imHeight
     tw = th = args.tile
 
-    # Frames in flight. A frame ends in a chain of small, latency-bound launches (deep bounce levels, fold) that leave
-    # most of the chip idle; with a second frame in flight (its own scene workspace, stream and framebuffer) that tail
-    # overlaps the next frame's large levels. Every frame is still rendered completely and checked below.
+    # Batches and calls in flight. A frame ends in a chain of small, latency-bound launches (deep bounce levels, fold)
+    # that leave most of the chip idle, and a small frame - or one rank's share of a frame - is bound by the host's
+    # launch rate. So (1) the steps are rendered B frames per library call (rt_render_batch_device: the frames' rays share
+    # every launch) and (2) two calls are in flight, each with its own scene workspace, stream and framebuffers. Every
+    # frame is still rendered completely and compared with the census frame below.
+    # ... as many as fill about one 8 M-sample pass of this rank (a batch of large frames would only add passes)
+    B = max(1, min(16, args.frames_per_batch, (8 << 20) // max(1, (W * H * params.spp) // world)))
+    cams = [cam] * B
+    frame_bytes = H * W * 3
+
     class Slot:
         pass
     slots = []
@@ -150,11 +160,14 @@ def main():
         sl.dev = dev if k == 0 else DeviceScene(fs, device=local, bvh=args.bvh)
         # the scene's own stream, seen by torch: renders, the RCCL gather and the untile are ordered on it
         sl.stream = torch.cuda.ExternalStream(sl.dev.stream(), device=torch.device("cuda", local))
-        sl.frame = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+        sl.frames = torch.zeros((B, H, W, 3), dtype=torch.uint8, device="cuda")
+        sl.frame = sl.frames[0]
+        sl.last_b = 0
         if world > 1:
             sl.n_slot = lib.rt_tiles_owned(W, H, tw, th, 0, world)       # part 0 owns the most tiles
-            sl.mine = torch.zeros((sl.n_slot * tw * th * 3,), dtype=torch.uint8, device="cuda")
-            sl.allt = torch.zeros((world * sl.n_slot * tw * th * 3,), dtype=torch.uint8, device="cuda") if rank == 0 else None
+            sl.part_bytes = sl.n_slot * tw * th * 3                       # one frame's tiles of one part
+            sl.mine = torch.zeros((B * sl.part_bytes,), dtype=torch.uint8, device="cuda")
+            sl.allt = torch.zeros((world * B * sl.part_bytes,), dtype=torch.uint8, device="cuda") if rank == 0 else None
             sl.gathered = list(sl.allt.chunk(world)) if rank == 0 else None     # the gather lands directly in the untile input
         slots.append(sl)
     stream = slots[0].stream.cuda_stream
@@ -172,16 +185,18 @@ def main():
         ref_frame = frame.clone()
     rays_per_frame = st.trace_calls + st.shadow_rays
 
-    def step(i):
+    def step(i, b=1):
+        """Call number i: the next b (<= B) frames, on slot i % slots."""
         sl = slots[i % len(slots)]
+        sl.last_b = b
         h = sl.stream.cuda_stream
         with torch.cuda.stream(sl.stream):
             if world == 1:
-                sl.dev.render_device(cam, params, sl.frame.data_ptr(), stream=h)
+                sl.dev.render_batch_device(cams[:b], params, sl.frames.data_ptr(), frame_bytes, stream=h)
                 return
-            sl.dev.render_tiles_device(cam, params, (tw, th), rank, world, sl.mine.data_ptr(), stream=h)
+            sl.dev.render_tiles_batch_device(cams[:b], params, (tw, th), rank, world, sl.mine.data_ptr(), sl.part_bytes, stream=h)
             if args.backend == "nccl":
-                dist.gather(sl.mine, sl.gathered, dst=0)
+                dist.gather(sl.mine, sl.gathered, dst=0)        # ONE exchange for the b frames
             else:       # gloo rehearsal: gloo gathers host tensors only
                 sl.stream.synchronize()
                 host = sl.mine.cpu()
@@ -189,9 +204,20 @@ def main():
                 dist.gather(host, hg, dst=0)
                 if rank == 0:
                     sl.allt.copy_(torch.cat(hg))
-            if rank == 0:
-                cabi.check(lib, lib.rt_untile_device(local, W, H, tw, th, world, sl.n_slot, C.c_void_p(sl.allt.data_ptr()),
-                                                     C.c_void_p(sl.frame.data_ptr()), C.c_void_p(h)))
+            if rank == 0:       # part q's tiles of frame k start at tile slot q * B * n_slot + k * n_slot
+                for k in range(b):
+                    cabi.check(lib, lib.rt_untile_device(local, W, H, tw, th, world, B * sl.n_slot,
+                                                         C.c_void_p(sl.allt.data_ptr() + k * sl.part_bytes),
+                                                         C.c_void_p(sl.frames[k].data_ptr()), C.c_void_p(h)))
+
+    def run_steps(n):
+        """n frames as ceil(n / B) calls."""
+        done, call = 0, 0
+        while done < n:
+            b = min(B, n - done)
+            step(call, b)
+            done += b
+            call += 1
 
     def sync():
         if world > 1:
@@ -215,14 +241,13 @@ def main():
     # untimed: W warmup steps, repeated (at most 8 times) while a scene is still learning its pass size
     adapt_rounds = 0
     for adapt_rounds in range(8):
-        for i in range(args.warmup):
-            step(i)
+        # (rounded up to whole batches on every slot, so that no workspace grows inside the timed region)
+        run_steps(-(-args.warmup // (B * len(slots))) * B * len(slots))
         sync()
         if not overflowed():
             break
     t = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
+    run_steps(args.steps)
     sync()
     elapsed = time.perf_counter() - t
     if overflowed():
@@ -249,12 +274,12 @@ def main():
                        "scene_build_s": round(build_s, 3), "bvh": args.bvh,
                        "bvh_build_s": round(dev.bvh_info().build_seconds, 4)},
         }
-        used = slots[:min(len(slots), args.steps + args.warmup)]
-        identical = all(bool(torch.equal(sl.frame, ref_frame)) for sl in used)
+        identical = all(bool(torch.equal(sl.frames[k], ref_frame)) for sl in slots for k in range(sl.last_b))
         out["frame_identical_to_1gpu"] = identical
         out["config"]["frames_in_flight"] = len(slots)
+        out["config"]["frames_per_batch"] = B
         out["config"]["pool_adapt_rounds"] = adapt_rounds
-        if world == 1 and len(slots) > 1:
+        if world == 1 and (len(slots) > 1 or B > 1):
             # latency view: the same frames one at a time (one workspace, one stream)
             t = time.perf_counter()
             for _ in range(args.steps):

@@ -11,7 +11,7 @@ print({k:d[k] for k in ('value','ms_per_step')}, d.get('one_frame_at_a_time'), d
 print({k:(round(v['avg_launch_ms'],4), v['launches_per_frame'], round(v['ms_per_frame_serial'],4)) for k,v in d['roofline']['kernels'].items()})
 PY
 for w in "$@"; do
-  timeout -k 10 600 python -u bench.py --workload $w --no-cpu-baseline --steps 10 --warmup 2 --watchdog 580 > gpurun_out/bench_$w.json 2> gpurun_out/bench_$w.err
+  timeout -k 10 600 python -u bench.py --workload $w --no-cpu-baseline --steps 32 --warmup 8 --watchdog 580 > gpurun_out/bench_$w.json 2> gpurun_out/bench_$w.err
   python - $w <<'PY'
 import json,sys; d=json.loads(open('gpurun_out/bench_%s.json'%sys.argv[1]).read().strip().splitlines()[-1])
 print(sys.argv[1], {k:d[k] for k in ('value','ms_per_step')}, d.get('one_frame_at_a_time'), d['roofline']['level0_launch_ms'])
