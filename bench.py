@@ -204,11 +204,10 @@ def main():
                 dist.gather(host, hg, dst=0)
                 if rank == 0:
                     sl.allt.copy_(torch.cat(hg))
-            if rank == 0:       # part q's tiles of frame k start at tile slot q * B * n_slot + k * n_slot
-                for k in range(b):
-                    cabi.check(lib, lib.rt_untile_device(local, W, H, tw, th, world, B * sl.n_slot,
-                                                         C.c_void_p(sl.allt.data_ptr() + k * sl.part_bytes),
-                                                         C.c_void_p(sl.frames[k].data_ptr()), C.c_void_p(h)))
+            if rank == 0:       # part q's tiles of frame k start at tile slot q * B * n_slot + k * n_slot; one launch
+                cabi.check(lib, lib.rt_untile_batch_device(local, W, H, tw, th, world, B * sl.n_slot, b, sl.part_bytes,
+                                                           frame_bytes, C.c_void_p(sl.allt.data_ptr()),
+                                                           C.c_void_p(sl.frames.data_ptr()), C.c_void_p(h)))
 
     def run_steps(n):
         """n frames as ceil(n / B) calls."""

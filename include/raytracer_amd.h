@@ -209,6 +209,12 @@ uint32_t rt_tiles_owned(uint32_t imWidth, uint32_t imHeight, uint32_t tile_w, ui
 int rt_untile_device(int device, uint32_t imWidth, uint32_t imHeight, uint32_t tile_w, uint32_t tile_h,
                      uint32_t n_parts, uint32_t part_stride_tiles, const uint8_t* d_tiles_all, uint8_t* d_bgr_out,
                      void* stream);
+/* The same for a batch (rt_render_tiles_batch_device): frame k's tiles of every part start in_frame_stride_bytes * k
+ * behind those of frame 0, frame k is written out_frame_stride_bytes * k behind d_bgr_out; one launch. */
+int rt_untile_batch_device(int device, uint32_t imWidth, uint32_t imHeight, uint32_t tile_w, uint32_t tile_h,
+                           uint32_t n_parts, uint32_t part_stride_tiles, uint32_t n_frames,
+                           uint64_t in_frame_stride_bytes, uint64_t out_frame_stride_bytes,
+                           const uint8_t* d_tiles_all, uint8_t* d_bgr_out, void* stream);
 
 /* Unit entry points used by the parity tests (each runs the same device functions the renderer uses). */
 

@@ -107,7 +107,7 @@ def u8ptr(a):
 EXPORTS = [
     "rt_scene_create", "rt_scene_create_ex", "rt_scene_destroy", "rt_render", "rt_render_device", "rt_render_tiles_device",
     "rt_render_batch_device", "rt_render_tiles_batch_device",
-    "rt_tiles_owned", "rt_untile_device", "rt_cast_rays", "rt_intersect", "rt_occluded", "rt_trace",
+    "rt_tiles_owned", "rt_untile_device", "rt_untile_batch_device", "rt_cast_rays", "rt_intersect", "rt_occluded", "rt_trace",
     "rt_scene_bvh_info", "rt_bvh_check", "rt_scene_bvh_check", "rt_scene_status", "rt_scene_stream", "rt_set_count_work", "rt_get_work", "rt_last_error", "rt_version",
 ]
 
@@ -150,6 +150,7 @@ def load(path=None):
     lib.rt_tiles_owned.argtypes = [u32] * 6
     lib.rt_tiles_owned.restype = u32
     lib.rt_untile_device.argtypes = [C.c_int, u32, u32, u32, u32, u32, u32, vp, vp, vp]
+    lib.rt_untile_batch_device.argtypes = [C.c_int, u32, u32, u32, u32, u32, u32, u32, C.c_uint64, C.c_uint64, vp, vp, vp]
     lib.rt_cast_rays.argtypes = [C.c_int, C.POINTER(rt_camera), C.POINTER(rt_params),
                                  C.POINTER(C.c_uint32), u32, FP]
     lib.rt_intersect.argtypes = [vp, C.c_int, FP, u32, C.POINTER(C.c_int32), FP, FP]

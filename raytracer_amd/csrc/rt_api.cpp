@@ -953,7 +953,13 @@ extern "C" int rt_render_tiles_batch_device(rt_scene* s, const rt_camera* cam, u
 
 extern "C" int rt_untile_device(int device, uint32_t W, uint32_t H, uint32_t tw, uint32_t th, uint32_t n_parts,
                                 uint32_t part_stride_tiles, const uint8_t* d_tiles, uint8_t* d_bgr, void* stream) {
-    if (!d_tiles || !d_bgr || !tw || !th || !n_parts || !W || !H) { rt_set_error("bad argument"); return RT_ERR_INVALID; }
+    return rt_untile_batch_device(device, W, H, tw, th, n_parts, part_stride_tiles, 1, 0, 0, d_tiles, d_bgr, stream);
+}
+
+extern "C" int rt_untile_batch_device(int device, uint32_t W, uint32_t H, uint32_t tw, uint32_t th, uint32_t n_parts,
+                                      uint32_t part_stride_tiles, uint32_t n_frames, uint64_t in_frame_stride_bytes,
+                                      uint64_t out_frame_stride_bytes, const uint8_t* d_tiles, uint8_t* d_bgr, void* stream) {
+    if (!d_tiles || !d_bgr || !tw || !th || !n_parts || !W || !H || !n_frames || n_frames > RT_MAX_BATCH) { rt_set_error("bad argument"); return RT_ERR_INVALID; }
     HIP_TRY(hipSetDevice(device));
     UntileArgs U{};
     U.W = W; U.H = H; U.tile_w = tw; U.tile_h = th;
@@ -961,6 +967,7 @@ extern "C" int rt_untile_device(int device, uint32_t W, uint32_t H, uint32_t tw,
     U.n_tiles = U.tiles_x * ((H + th - 1) / th);
     U.n_parts = n_parts;
     U.part_stride = part_stride_tiles;
+    U.n_frames = n_frames; U.in_stride = in_frame_stride_bytes; U.out_stride = out_frame_stride_bytes;
     launch_untile(U, d_tiles, d_bgr, static_cast<hipStream_t>(stream));
     HIP_TRY(hipGetLastError());
     return RT_OK;

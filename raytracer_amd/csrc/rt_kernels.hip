@@ -1200,6 +1200,8 @@ __global__ __launch_bounds__(256) void k_resolve_rgb(DScene S, LevelArgs A, floa
 __global__ __launch_bounds__(256) void k_untile(UntileArgs U, const uint8_t* __restrict__ tiles, uint8_t* __restrict__ out) {
     const uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= (uint64_t)U.W * U.H) return;
+    tiles += (uint64_t)blockIdx.y * U.in_stride;        // frame of a batch
+    out += (uint64_t)blockIdx.y * U.out_stride;
     const uint32_t x = (uint32_t)(p % U.W), y = (uint32_t)(p / U.W);
     const uint32_t tx = x / U.tile_w, ty = y / U.tile_h;
     const uint32_t T = ty * U.tiles_x + tx;
@@ -1344,7 +1346,7 @@ void launch_resolve_rgb(const DScene& S, const LevelArgs& A, float* rgb, hipStre
 }
 void launch_untile(const UntileArgs& U, const uint8_t* tiles, uint8_t* out, hipStream_t st) {
     const uint64_t n = (uint64_t)U.W * U.H;
-    hipLaunchKernelGGL(k_untile, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, U, tiles, out);
+    hipLaunchKernelGGL(k_untile, dim3((uint32_t)((n + 255) / 256), U.n_frames ? U.n_frames : 1u), dim3(256), 0, st, U, tiles, out);
 }
 void launch_cast_rays(const DCamera& cam, const float* aa, uint32_t spp, const uint32_t* xy, uint32_t n, float* out,
                       hipStream_t st) {

@@ -120,6 +120,9 @@ struct LevelArgs {
 struct UntileArgs {
     uint32_t W, H, tile_w, tile_h, tiles_x, n_tiles, n_parts;
     uint32_t part_stride;   // tile slots between parts; 0 = packed
+    uint32_t n_frames;      // batch: frames per launch (blockIdx.y)
+    uint64_t in_stride;     // batch: bytes between consecutive frames' tiles (within a part)
+    uint64_t out_stride;    // batch: bytes between consecutive output frames
 };
 
 // Kernel forms: one ray per lane (suspends at meshes), one ray per quad from the start, one per quad resuming the queue.

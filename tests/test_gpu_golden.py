@@ -185,3 +185,17 @@ def test_batch_equals_single_frames():
         parts.append(t.cpu().numpy().reshape(5, tstride))
     for k in range(5):
         assert np.array_equal(tiling.untile([pp[k] for pp in parts], W, H, tw, th), singles[k]), k
+    # ... and untiled on the device in one launch, from the layout a gather leaves: [part][frame][tile slots]
+    n_slot = dev.lib.rt_tiles_owned(W, H, tw, th, 0, 3)
+    part_bytes = n_slot * tw * th * 3
+    allt = torch.zeros((3, 5, part_bytes), dtype=torch.uint8, device="cuda")
+    for part in range(3):
+        dev.render_tiles_batch_device(cams, p, (tw, th), part, 3, allt[part].data_ptr(), part_bytes)
+    dev.status()
+    frames = torch.zeros((5, H, W, 3), dtype=torch.uint8, device="cuda")
+    cabi.check(dev.lib, dev.lib.rt_untile_batch_device(0, W, H, tw, th, 3, 5 * n_slot, 5, part_bytes, W * H * 3,
+                                                       C.c_void_p(allt.data_ptr()), C.c_void_p(frames.data_ptr()), None))
+    torch.cuda.synchronize()
+    got = frames.cpu().numpy()
+    for k in range(5):
+        assert np.array_equal(got[k], singles[k]), k
