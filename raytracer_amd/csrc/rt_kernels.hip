@@ -553,7 +553,7 @@ __device__ __forceinline__ bool map_pixel(const PixelMap& pm, uint64_t q, uint32
 // Waves per SIMD the register allocator must leave room for (512 VGPRs per lane: 4 waves = 128 VGPRs each, ...). The
 // traversal is a chain of dependent loads, so more resident waves pay even where a few values spill to scratch.
 #ifndef RT_WPE_SQ
-#define RT_WPE_SQ 4
+#define RT_WPE_SQ 5      // 96 VGPRs: a few values spill; measured with batched frames 0.571 -> 0.548 ms (bunny), 82.3 -> 78.8 ms (c4)
 #endif
 #ifndef RT_WPE_EQ
 #define RT_WPE_EQ 5
