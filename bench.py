@@ -101,7 +101,7 @@ def main():
                     help="rehearsal only: every rank uses GPU 0 (needs --backend gloo)")
     ap.add_argument("--frames-in-flight", type=int, default=2,
                     help="frames rendered concurrently (each in its own scene workspace and stream); 1 = one at a time")
-    ap.add_argument("--frames-per-batch", type=int, default=8,
+    ap.add_argument("--frames-per-batch", type=int, default=16,
                     help="frames (steps) rendered per library call, rt_render_batch_device: every launch then carries "
                          "that many frames' rays (1..16; 1 = one call per frame)")
     ap.add_argument("--bvh", default="host", choices=("host", "device"),
