@@ -350,7 +350,10 @@ def main():
                     ms0[k] += s2.kernel_ms_by[k]; n0[k] += s2.kernel_launches_by[k]
             dev.render_device(cam, params, frame.data_ptr(), stream=stream)      # leave the full frame in the buffer
             torch.cuda.synchronize()
-            rocprof_names = ("k_extend_wide<0, false>", "k_shade_wide<false, false>", "k_extend_quad<0, false, false>",
+            # (a scene whose level 0 is traversed as packets has no quad launches at level 0: the per-lane kernels'
+            # PACKET instantiations do the whole level)
+            pk = "true" if (fs.num_faces and not n0[2]) else "false"
+            rocprof_names = (f"k_extend_wide<0, false, {pk}>", f"k_shade_wide<false, false, {pk}>", "k_extend_quad<0, false, false>",
                              "k_shade_quad<1, false, false>", "k_shade_quad<2, false, false>")
             dk = max(range(NK), key=lambda k: ms0[k] / max(n0[k], 1))
             avg = ms0[dk] / n0[dk]

@@ -61,6 +61,7 @@ static uint32_t pass_samples() {      // level-0 samples per pass (RT_PASS_LOG2 
 #define RT_PASS_SAMPLES pass_samples()
 #define RT_POOL_FACTOR 6u             // node pool = 6x the pass size when materials bounce (level 0 + 5x for deeper levels)
 #define RT_MAX_TIMED 2048
+#define RT_PACKET_MAX_FACES 1000000u
 #define RT_MAX_GRAPHS 8
 enum { RT_K_EXTEND_WIDE = 0, RT_K_SHADE_WIDE = 1, RT_K_EXTEND_QUAD = 2, RT_K_SHADE_QUAD = 3, RT_K_SHADE_PARKED = 4 };
 #define RT_LEVEL_GRID 8192u           // workgroups of a level >= 1 launch (grid-stride over the device-side count)
@@ -250,6 +251,11 @@ extern "C" int rt_scene_create_ex(const rt_flat_scene* sc, int device, uint32_t 
         if (!(e >= 0.0f && e <= float(RT_POW_MAX_INT) && float(int(e)) == e)) s->d.generic_pow = 1;
     }
     s->d.n_lights = sc->n_lights;
+    // Level 0 as packets (packet_traverse): pays while a 64-sample block's rays share most of their path through the
+    // tree, i.e. while triangles are not much smaller than pixels. Millions of faces: quads. RT_PACKET=0/1 overrides.
+    s->d.packet = (sc->n_models > 0 && sc->n_faces <= RT_PACKET_MAX_FACES) ? 1u : 0u;
+    if (const char* e = std::getenv("RT_PACKET")) s->d.packet = (std::atoi(e) != 0 && sc->n_models > 0) ? 1u : 0u;
+    s->d.pad = 0;
     if ((rc = upload(s, objs.data(), objs.size(), &s->d.objects)) != RT_OK) return fail(rc);
     if ((rc = upload(s, models.data(), models.size(), &s->d.models)) != RT_OK) return fail(rc);
     if ((rc = upload(s, sc->materials, size_t(sc->n_materials), &s->d.materials)) != RT_OK) return fail(rc);
@@ -571,14 +577,16 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
                 }
                 if ((rc = timed_launch(J, sa, RT_K_EXTEND_WIDE, [&] { launch_extend(src, RT_FORM_WIDE, s->count_work, s->d, B, lv == 0 ? grid0 : RT_LEVEL_GRID, sa); })) != RT_OK) return rc;
                 if (overlap) HIP_TRY(hipEventRecord(s->ev_sync[2 * lv], sa));
-                if (meshes) {
+                // level 0 of a packet scene: the per-lane kernels traverse the meshes themselves, nothing is suspended
+                const bool quads = meshes && !(lv == 0 && s->d.packet);
+                if (quads) {
                     B.wave_log = (lv == log_level) ? wave_log : nullptr;
                     if ((rc = timed_launch(J, sa, RT_K_EXTEND_QUAD, [&] { launch_extend(src, RT_FORM_QUAD_RESUME, s->count_work, s->d, B, lv == 0 ? grid0q : 4u * RT_LEVEL_GRID, sa); })) != RT_OK) return rc;
                     if (overlap) HIP_TRY(hipEventRecord(s->ev_sync[2 * lv + 1], sa));
                 }
                 const int ev_w = 2 * lv;
                 if ((rc = shade(RT_FORM_WIDE, lv, lv, ev_w)) != RT_OK) return rc;
-                if (meshes) {
+                if (quads) {
                     if ((rc = shade(RT_FORM_QUAD_RESUME, lv, lv, ev_w)) != RT_OK) return rc;
                     if ((rc = shade(RT_FORM_QUAD_PARKED, lv, lv, 2 * lv + 1)) != RT_OK) return rc;
                 }

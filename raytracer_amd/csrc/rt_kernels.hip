@@ -309,6 +309,84 @@ __device__ __forceinline__ void quad_traverse(const DScene& S, uint32_t root, bo
     out.t = best; out.u = bu; out.v = bv; out.face = face;
 }
 
+// ---- packet traversal: the wave's (up to) 64 rays, one per lane, walk the tree TOGETHER --------------------------
+// For rays that are coherent - the primary rays of an 8x8-pixel block and the shadow rays of their hits - most of the
+// tree a ray visits is the tree its neighbours visit. The packet visits a node when ANY of its rays reaches it: the
+// node (128 B) and the leaf blocks come in by SCALAR loads (one address per wave, no vector-memory traffic at all), the
+// four children are slab-tested by every lane against its own ray and its own culling distance, the children that
+// some ray hit are visited nearest first (by the distance of the first ray that hit each), and the traversal stack is
+// one per wave, kept across the lanes of one VGPR (entry k in lane k: a select on the lane number / v_readlane).
+// Per 64 rays that is a third of the instructions and dependent loads of four 16-ray quad batches. Same results: a
+// lane only ever sees the triangles of leaves whose box its own ray hit or, superfluously, did not - the accepted hit
+// is still the lexicographic minimum of (t, original face index) over the triangles its ray hits (closest), or
+// "some triangle with EPS < t < tmax" (ANY).
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ void packet_traverse(const DScene& S, uint32_t root, bool have, const Ray& ray, float tmax,
+                                                QuadHit& out, Work& wk) {
+    const V3 inv = mk(safe_rcp(ray.d.x), safe_rcp(ray.d.y), safe_rcp(ray.d.z));
+    const V3 ood = mk(ray.o.x * inv.x, ray.o.y * inv.y, ray.o.z * inv.z);
+    float best = ANY ? tmax : FLT_MAX, bu = 0, bv = 0;
+    uint32_t face = 0xFFFFFFFFu;
+    bool live = have;                       // ANY: cleared once the lane's ray is occluded
+    int stack = 0;                          // lane k = stack entry k
+    const uint32_t lane = lane_id();
+    uint32_t sp = 0;
+    uint32_t cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)(__ballot(have) ? root : RT_DONE));   // RT_NO_CHILD == RT_DONE
+    while (cur != RT_DONE) {
+        if (!(cur & RT_LEAF_BIT)) {
+            const RT_CONSTANT u32x4* np = (const RT_CONSTANT u32x4*)(const void*)(S.nodes) + 8u * (size_t)cur;
+            if (COUNT) { wk.nodes += live; wk.wave_nodes += wave_once(); }
+            const float cull = ANY ? best : best * 1.000001f;
+            uint32_t key[4], ref[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float4 a = as_f4(np[c]), b = as_f4(np[4 + c]);
+                ref[c] = __float_as_uint(a.w);
+                bool h;
+                const float tn = slab(a.x, a.y, a.z, b.x, b.y, b.z, inv, ood, cull, h);
+                const unsigned long long m = __ballot(h && live && ref[c] != RT_NO_CHILD);
+                // distance of the first ray that hits the child (tn >= 0: its bits order like its value); none: last
+                key[c] = m ? (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(tn), __ffsll((long long)m) - 1) : 0xFFFFFFFFu;
+            }
+            // sort the four (key, ref) pairs, all wave-uniform: 5 compare-exchanges
+#define RT_CSWAP(i, j) { const bool sw = key[j] < key[i]; const uint32_t k0_ = sw ? key[j] : key[i], k1_ = sw ? key[i] : key[j]; \
+                         const uint32_t r0_ = sw ? ref[j] : ref[i], r1_ = sw ? ref[i] : ref[j]; key[i] = k0_; key[j] = k1_; ref[i] = r0_; ref[j] = r1_; }
+            RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
+#undef RT_CSWAP
+            // the farthest goes in first, the nearest is visited next
+            if (key[3] != 0xFFFFFFFFu) { stack = lane == sp ? (int)ref[3] : stack; ++sp; }
+            if (key[2] != 0xFFFFFFFFu) { stack = lane == sp ? (int)ref[2] : stack; ++sp; }
+            if (key[1] != 0xFFFFFFFFu) { stack = lane == sp ? (int)ref[1] : stack; ++sp; }
+            if (key[0] != 0xFFFFFFFFu) cur = ref[0];
+            else if (sp) { --sp; cur = (uint32_t)__builtin_amdgcn_readlane(stack, (int)sp); }
+            else cur = RT_DONE;
+        } else {
+            const uint32_t cnt = ((cur >> 27) & 15u) + 1u;
+            const RT_CONSTANT u32x4* lp = (const RT_CONSTANT u32x4*)(const void*)(S.leaves) + 12u * (size_t)(cur & RT_LEAF_START_MASK);
+            if (COUNT) { wk.tris += live ? cnt : 0u; wk.wave_tris += wave_once(); }
+#pragma unroll
+            for (uint32_t t = 0; t < RT_MAX_LEAF_TRIS; ++t) {
+                if (t < cnt) {                                                                   // wave-uniform
+                    const float4 q0 = as_f4(lp[t]), q1 = as_f4(lp[4 + t]), q2 = as_f4(lp[8 + t]);
+                    float tt, u, v;
+                    if (live && tri_isect(f4xyz(q0), f4xyz(q1), f4xyz(q2), ray, tt, u, v)) {
+                        const uint32_t f = __float_as_uint(q0.w);
+                        if (ANY) {
+                            if (tt < tmax) { face = 0; live = false; }
+                        } else if (tt < best || (tt == best && f < face)) {
+                            best = tt; bu = u; bv = v; face = f;
+                        }
+                    }
+                }
+            }
+            if (ANY && __ballot(live) == 0) cur = RT_DONE;
+            else if (sp) { --sp; cur = (uint32_t)__builtin_amdgcn_readlane(stack, (int)sp); }
+            else cur = RT_DONE;
+        }
+    }
+    out.t = best; out.u = bu; out.v = bv; out.face = face;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // The two object loops of trace(), each in two forms:
 //   QUAD = false  one ray per lane (64 per wave). Spheres and planes are tested in place; a ray that passes a mesh's
@@ -328,7 +406,7 @@ struct HitState { float dist; V3 n; int cur; uint32_t mat; float tmpdist; };
 // Closest-hit loop (reference src/raytracer.cpp:292-300): objects in scene order, strict <. Returns -1 when the loop
 // ran to its end, else (QUAD = false only) the index of the mesh object the ray suspended at, with `h` as it was
 // before that object.
-template <bool QUAD, bool COUNT>
+template <bool QUAD, bool COUNT, bool PACKET = false>
 __device__ __forceinline__ int closest_loop(const DScene& S, const Ray& ray, bool alive, uint32_t k0, HitState& h,
                                             uint32_t* qs, Work& wk) {
     int susp = -1;
@@ -357,14 +435,19 @@ __device__ __forceinline__ int closest_loop(const DScene& S, const Ray& ray, boo
                 if (COUNT) wk.spheres += need && counter;
                 need = need && sphere_gate(m.bb, ray);
             }
-            if (!QUAD) {
+            if (!QUAD && !PACKET) {
                 if (need) susp = (int)k;
                 else if (go) h.tmpdist = FLT_MAX;
             } else {
                 if (go) h.tmpdist = FLT_MAX;
-                if (need) {
-                    QuadHit q;
+                QuadHit q;
+                q.face = 0xFFFFFFFFu; q.t = 0; q.u = 0; q.v = 0;
+                if (PACKET) {
+                    if (__ballot(need)) packet_traverse<false, COUNT>(S, m.root, need, ray, FLT_MAX, q, wk);
+                } else if (need) {
                     quad_traverse<false, COUNT>(S, m.root, true, ray, FLT_MAX, q, qs, wk);
+                }
+                if (need) {
                     if (q.face != 0xFFFFFFFFu) {
                         const float4* np = reinterpret_cast<const float4*>(S.normals + q.face);
                         const V3 n0 = f4xyz(np[0]), n1 = f4xyz(np[1]), n2 = f4xyz(np[2]);
@@ -388,7 +471,7 @@ __device__ __forceinline__ int closest_loop(const DScene& S, const Ray& ray, boo
 
 // Shadow loop (reference src/raytracer.cpp:319-325): any object with hit && tmpdist < ldist; the loop breaks at the
 // first one, so later objects no longer touch tmpdist. `susp` as in closest_loop.
-template <bool QUAD, bool COUNT>
+template <bool QUAD, bool COUNT, bool PACKET = false>
 __device__ __forceinline__ bool occluded_loop(const DScene& S, const Ray& ray, bool alive, uint32_t k0, float ldist,
                                               float& tmpdist, int& susp, uint32_t* qs, Work& wk) {
     V3 tmpnormal;
@@ -421,15 +504,18 @@ __device__ __forceinline__ bool occluded_loop(const DScene& S, const Ray& ray, b
                 if (COUNT) wk.spheres += need && counter;
                 need = need && sphere_gate(m.bb, ray);
             }
-            if (!QUAD) {
+            if (!QUAD && !PACKET) {
                 if (need) susp = (int)k;
                 else if (go) tmpdist = FLT_MAX;   // Model::intersect leaves FLT_MAX in dist on a miss (primitives.cpp:368)
             } else {
-                if (need) {
-                    QuadHit q;
+                QuadHit q;
+                q.face = 0xFFFFFFFFu;
+                if (PACKET) {
+                    if (__ballot(need)) packet_traverse<true, COUNT>(S, m.root, need, ray, ldist, q, wk);
+                } else if (need) {
                     quad_traverse<true, COUNT>(S, m.root, true, ray, ldist, q, qs, wk);
-                    in = q.face != 0xFFFFFFFFu;
                 }
+                if (need) in = q.face != 0xFFFFFFFFu;
                 if (go && !in) tmpdist = FLT_MAX;
             }
         }
@@ -563,6 +649,9 @@ __device__ __forceinline__ bool map_pixel(const PixelMap& pm, uint64_t q, uint32
 #endif
 #ifndef RT_WPE_EW
 #define RT_WPE_EW 7
+#endif
+#ifndef RT_WPE_PK
+#define RT_WPE_PK 5      // the per-lane kernels when they carry the packet traversal
 #endif
 #define RT_RUN_LOG2 3u    // see group_of: runs of 8 groups (measured: 1, 2, 4 and 16 within 3 %; 64+ and one strip per CU 5-20 % slower). Experiments: RT_DEBUG_SKIP = run_log2 << 8
 #define NODE_HIT 4u      // has a hit record: k_shade computes its colour
@@ -847,8 +936,8 @@ __device__ __forceinline__ void locate(const Groups& G, uint32_t grp, uint32_t& 
 }
 
 // k_extend_wide: one ray per lane. Rays that never reach a mesh are finished here; the others are queued.
-template <int SRC, bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WPE_EW))) void k_extend_wide(DScene S, LevelArgs A) {
+template <int SRC, bool COUNT, bool PACKET>
+__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(PACKET ? RT_WPE_PK : RT_WPE_EW))) void k_extend_wide(DScene S, LevelArgs A) {
     const bool level0 = SRC != 1;
     const ShardView v = shard_view(A, A.level, A.level);
     const Groups G = level0 ? make_groups_dense<false>(A.n0, A.chunk_log2) : make_groups<false>(v.start, v.cnt);
@@ -866,7 +955,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WPE
         const bool valid = active && fetch_ray<SRC>(A, 0, i, ray);
         HitState h = fresh_hit();
         int susp = -1;
-        if (!(A.debug & 2u)) susp = closest_loop<false, COUNT>(S, ray, valid, 0, h, nullptr, wk);
+        if (!(A.debug & 2u)) susp = closest_loop<false, COUNT, PACKET>(S, ray, valid, 0, h, nullptr, wk);
         const bool parked = susp >= 0;
         ShardCounters* sc = A.sc + shard;
         uint32_t qslot = 0;
@@ -961,7 +1050,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WPE
 // Light loop of trace() (reference src/raytracer.cpp:311-345) for one hit, starting at light li0 / object k0 of its
 // shadow loop (0/0, or where the per-lane kernel suspended). Writes node_a[i]; on suspension (QUAD = false) node_a[i]
 // holds {colour so far, tmpdist} and `parked` gets (li << 16) | k. Convergent.
-template <bool QUAD, bool COUNT, bool GPOW>
+template <bool QUAD, bool COUNT, bool GPOW, bool PACKET = false>
 __device__ __forceinline__ void shade_ray(const DScene& S, const LevelArgs& A, uint32_t i, uint4 b, bool hit, bool writer,
                                           V3 hitNormal, V3 hitPt, float rCoef, float tmpdist, uint32_t li0, uint32_t k0,
                                           bool resumed, V3 color, uint32_t* qs, Work& wk, uint32_t& n_shadow, int& parked) {
@@ -983,7 +1072,7 @@ __device__ __forceinline__ void shade_ray(const DScene& S, const LevelArgs& A, u
         sr.d = lv;
         n_shadow += live && writer && !(resumed && li == li0);      // a resumed ray was counted when it was shot
         int sk;
-        const bool occ = occluded_loop<QUAD, COUNT>(S, sr, live && !(A.debug & 1u), li == li0 ? k0 : 0u, ldist, tmpdist, sk, qs, wk);
+        const bool occ = occluded_loop<QUAD, COUNT, PACKET>(S, sr, live && !(A.debug & 1u), li == li0 ? k0 : 0u, ldist, tmpdist, sk, qs, wk);
         if (live && sk >= 0) { parked = (int)((li << 16) | (uint32_t)sk); continue; }
         if (!live || occ) continue;
         if (isnan3(hitNormal)) { red = true; continue; }                                 // raytracer.cpp:330-332
@@ -1030,8 +1119,8 @@ __device__ __forceinline__ void flush_shadow(const LevelArgs& A, uint32_t n_shad
 
 // k_shade_wide: light loop, one hit per lane, for the hits of levels A.level..A.level_hi. Hits whose shadow rays never
 // reach a mesh are finished here; the others are queued (queue of A.level) at the point they stopped.
-template <bool COUNT, bool GPOW>
-__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WPE_SW))) void k_shade_wide(DScene S, LevelArgs A) {
+template <bool COUNT, bool GPOW, bool PACKET>
+__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(PACKET ? RT_WPE_PK : RT_WPE_SW))) void k_shade_wide(DScene S, LevelArgs A) {
     const bool level0 = A.level == 0;                 // then level_hi == 0: level 0 is not part of a range
     const ShardView v = shard_view(A, A.level, A.level_hi);
     const Groups G = level0 ? make_groups_dense<false>(A.n0, A.chunk_log2) : make_groups<false>(v.start, v.cnt);
@@ -1049,7 +1138,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WPE
         float4 hn = make_float4(0, 0, 0, 0), hp = make_float4(0, 0, 0, 0);
         if (hit) { hn = A.hit_n[i]; hp = A.hit_p[i]; }
         int parked;
-        shade_ray<false, COUNT, GPOW>(S, A, i, b, hit, true, f4xyz(hn), f4xyz(hp), hp.w, hn.w, 0, 0, false, mk(0, 0, 0), nullptr, wk,
+        shade_ray<false, COUNT, GPOW, PACKET>(S, A, i, b, hit, true, f4xyz(hn), f4xyz(hp), hp.w, hn.w, 0, 0, false, mk(0, 0, 0), nullptr, wk,
                                 n_shadow, parked);
         if (level0) {       // mark; hit_n.w (tmpdist at the start of the light loop) is not needed again: keep the resume point there
             if (parked >= 0) { A.node_b[i].w = b.w | NODE_SPARKED; A.hit_n[i].w = __uint_as_float((uint32_t)parked); }
@@ -1333,8 +1422,13 @@ template <int SRC>
 static void launch_extend_src(int form, bool count, const DScene& S, const LevelArgs& A, dim3 g, hipStream_t st) {
     dim3 b(RT_BLOCK);
     if (form == RT_FORM_WIDE) {
-        if (count) hipLaunchKernelGGL((k_extend_wide<SRC, true>), g, b, 0, st, S, A);
-        else hipLaunchKernelGGL((k_extend_wide<SRC, false>), g, b, 0, st, S, A);
+        if (SRC == 0 && S.packet) {     // primary rays: coherent, traversed as packets in the per-lane kernel itself
+            if (count) hipLaunchKernelGGL((k_extend_wide<SRC, true, true>), g, b, 0, st, S, A);
+            else hipLaunchKernelGGL((k_extend_wide<SRC, false, true>), g, b, 0, st, S, A);
+        } else {
+            if (count) hipLaunchKernelGGL((k_extend_wide<SRC, true, false>), g, b, 0, st, S, A);
+            else hipLaunchKernelGGL((k_extend_wide<SRC, false, false>), g, b, 0, st, S, A);
+        }
     } else if (form == RT_FORM_QUAD_FRESH) {
         if (count) hipLaunchKernelGGL((k_extend_quad<SRC, true, true>), g, b, 0, st, S, A);
         else hipLaunchKernelGGL((k_extend_quad<SRC, true, false>), g, b, 0, st, S, A);
@@ -1350,7 +1444,11 @@ void launch_extend(int src, int form, bool count, const DScene& S, const LevelAr
 }
 template <bool COUNT, bool GPOW>
 static void launch_shade_t(int form, const DScene& S, const LevelArgs& A, dim3 g, dim3 b, hipStream_t st) {
-    if (form == RT_FORM_WIDE) hipLaunchKernelGGL((k_shade_wide<COUNT, GPOW>), g, b, 0, st, S, A);
+    if (form == RT_FORM_WIDE) {
+        // the hits of primary rays: their shadow rays are coherent too (rt_trace's caller-supplied rays need not be)
+        if (S.packet && A.level == 0 && !A.user_rays) hipLaunchKernelGGL((k_shade_wide<COUNT, GPOW, true>), g, b, 0, st, S, A);
+        else hipLaunchKernelGGL((k_shade_wide<COUNT, GPOW, false>), g, b, 0, st, S, A);
+    }
     else if (form == RT_FORM_QUAD_FRESH) hipLaunchKernelGGL((k_shade_quad<0, COUNT, GPOW>), g, b, 0, st, S, A);
     else if (form == RT_FORM_QUAD_RESUME) hipLaunchKernelGGL((k_shade_quad<1, COUNT, GPOW>), g, b, 0, st, S, A);
     else hipLaunchKernelGGL((k_shade_quad<2, COUNT, GPOW>), g, b, 0, st, S, A);

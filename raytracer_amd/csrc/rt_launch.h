@@ -18,6 +18,8 @@ struct DScene {
     uint32_t n_lights;
     uint32_t debug;              // timing experiments only (RT_DEBUG_SKIP)
     uint32_t generic_pow;        // a material's specRefExp is not an integer in [0, RT_POW_MAX_INT]: shade kernels with pow()
+    uint32_t packet;             // level 0 (primary rays and their shadow rays) traverses meshes as 64-ray packets in the per-lane kernels
+    uint32_t pad;
     const DModel* models;
     const rt_material* materials;
     const float4* lights;        // 2 per light: pos, color
