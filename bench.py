@@ -99,8 +99,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal only: every rank uses GPU 0 (needs --backend gloo)")
-    ap.add_argument("--frames-in-flight", type=int, default=2,
-                    help="frames rendered concurrently (each in its own scene workspace and stream); 1 = one at a time")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="library calls in flight (each in its own scene workspace and stream); 0 = 2, or 1 when one frame is several passes already")
     ap.add_argument("--frames-per-batch", type=int, default=16,
                     help="frames (steps) rendered per library call, rt_render_batch_device: every launch then carries "
                          "that many frames' rays (1..16; 1 = one call per frame)")
@@ -155,7 +155,10 @@ def main():
     class Slot:
         pass
     slots = []
-    for k in range(max(1, args.frames_in_flight)):
+    # a frame of several 8 M-sample passes fills the chip by itself: a second call in flight only competes for the caches
+    # (4K 16 spp glass scene: 55 ms one call at a time, 67 ms with two)
+    in_flight = args.frames_in_flight or (1 if (W * H * params.spp) // world >= 2 * (8 << 20) else 2)
+    for k in range(in_flight):
         sl = Slot()
         sl.dev = dev if k == 0 else DeviceScene(fs, device=local, bvh=args.bvh)
         # the scene's own stream, seen by torch: renders, the RCCL gather and the untile are ordered on it

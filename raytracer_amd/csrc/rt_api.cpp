@@ -61,7 +61,6 @@ static uint32_t pass_samples() {      // level-0 samples per pass (RT_PASS_LOG2 
 #define RT_PASS_SAMPLES pass_samples()
 #define RT_POOL_FACTOR 6u             // node pool = 6x the pass size when materials bounce (level 0 + 5x for deeper levels)
 #define RT_MAX_TIMED 2048
-#define RT_PACKET_MAX_FACES 1000000u
 #define RT_MAX_GRAPHS 8
 enum { RT_K_EXTEND_WIDE = 0, RT_K_SHADE_WIDE = 1, RT_K_EXTEND_QUAD = 2, RT_K_SHADE_QUAD = 3, RT_K_SHADE_PARKED = 4 };
 #define RT_LEVEL_GRID 8192u           // workgroups of a level >= 1 launch (grid-stride over the device-side count)
@@ -81,6 +80,7 @@ struct rt_scene {
     // workspace
     uint32_t pool_cap = 0, sub_cap = 0, ws_n0 = 0;
     uint32_t n_leaves = 0, bvh_stack = 0;
+    bool packet_auto = true;             // DScene::packet chosen per frame (render_frame)
     bool built_on_device = false;
     double build_seconds = 0;
     std::vector<uint32_t> model_roots;
@@ -251,10 +251,11 @@ extern "C" int rt_scene_create_ex(const rt_flat_scene* sc, int device, uint32_t 
         if (!(e >= 0.0f && e <= float(RT_POW_MAX_INT) && float(int(e)) == e)) s->d.generic_pow = 1;
     }
     s->d.n_lights = sc->n_lights;
-    // Level 0 as packets (packet_traverse): pays while a 64-sample block's rays share most of their path through the
-    // tree, i.e. while triangles are not much smaller than pixels. Millions of faces: quads. RT_PACKET=0/1 overrides.
-    s->d.packet = (sc->n_models > 0 && sc->n_faces <= RT_PACKET_MAX_FACES) ? 1u : 0u;
-    if (const char* e = std::getenv("RT_PACKET")) s->d.packet = (std::atoi(e) != 0 && sc->n_models > 0) ? 1u : 0u;
+    // Level 0 as packets (packet_traverse). Measured faster even where triangles are much smaller than pixels (10 M
+    // faces at 1080p 4 spp: 7.4 -> 6.4 ms/frame). RT_PACKET=0 in the environment turns it off (experiments).
+    s->packet_auto = true;
+    s->d.packet = sc->n_models > 0 ? 1u : 0u;
+    if (const char* e = std::getenv("RT_PACKET")) { s->d.packet = sc->n_models > 0 ? uint32_t(std::atoi(e)) : 0u; s->packet_auto = false; }
     s->d.pad = 0;
     if ((rc = upload(s, objs.data(), objs.size(), &s->d.objects)) != RT_OK) return fail(rc);
     if ((rc = upload(s, models.data(), models.size(), &s->d.models)) != RT_OK) return fail(rc);
@@ -578,7 +579,7 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
                 if ((rc = timed_launch(J, sa, RT_K_EXTEND_WIDE, [&] { launch_extend(src, RT_FORM_WIDE, s->count_work, s->d, B, lv == 0 ? grid0 : RT_LEVEL_GRID, sa); })) != RT_OK) return rc;
                 if (overlap) HIP_TRY(hipEventRecord(s->ev_sync[2 * lv], sa));
                 // level 0 of a packet scene: the per-lane kernels traverse the meshes themselves, nothing is suspended
-                const bool quads = meshes && !(lv == 0 && s->d.packet);
+                const bool quads = meshes && !((lv == 0 && s->d.packet) || s->d.packet >= 2);
                 if (quads) {
                     B.wave_log = (lv == log_level) ? wave_log : nullptr;
                     if ((rc = timed_launch(J, sa, RT_K_EXTEND_QUAD, [&] { launch_extend(src, RT_FORM_QUAD_RESUME, s->count_work, s->d, B, lv == 0 ? grid0q : 4u * RT_LEVEL_GRID, sa); })) != RT_OK) return rc;
@@ -662,6 +663,10 @@ static int render_frame(rt_scene* s, const rt_camera* cam, uint32_t n_frames, co
     int rc = ensure_workspace(s, std::max(((uint32_t(std::min<uint64_t>(total_px, full_px)) + 63u) & ~63u) * spp, s->ws_min_n0));
     if (rc != RT_OK) return rc;
 
+    // Packets below level 0 too (the large levels' per-lane kernels) when a 64-entry block holds the children of few
+    // pixels, i.e. at 16+ samples per pixel: measured 1426 -> 844 ms (level 0) -> 791 ms (all levels) per frame on the 10 M-
+    // triangle scene at 64 spp and 78 -> 69 -> 55..67 ms on the 4K 16 spp glass scene, but 6.3 -> 10.9 ms at 4 spp.
+    if (s->packet_auto && s->n_models) s->d.packet = spp >= 16 ? 2u : 1u;
     FrameJob J{};
     J.s = s; J.st = st; J.d_out = d_out; J.timed = stats != nullptr;
     LevelArgs& B = J.base;

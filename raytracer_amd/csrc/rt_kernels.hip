@@ -1422,7 +1422,7 @@ template <int SRC>
 static void launch_extend_src(int form, bool count, const DScene& S, const LevelArgs& A, dim3 g, hipStream_t st) {
     dim3 b(RT_BLOCK);
     if (form == RT_FORM_WIDE) {
-        if (SRC == 0 && S.packet) {     // primary rays: coherent, traversed as packets in the per-lane kernel itself
+        if ((SRC == 0 && S.packet) || (SRC == 1 && S.packet >= 2)) {     // primary rays: coherent, traversed as packets in the per-lane kernel itself (2: experiment, deeper levels too)
             if (count) hipLaunchKernelGGL((k_extend_wide<SRC, true, true>), g, b, 0, st, S, A);
             else hipLaunchKernelGGL((k_extend_wide<SRC, false, true>), g, b, 0, st, S, A);
         } else {
@@ -1446,7 +1446,7 @@ template <bool COUNT, bool GPOW>
 static void launch_shade_t(int form, const DScene& S, const LevelArgs& A, dim3 g, dim3 b, hipStream_t st) {
     if (form == RT_FORM_WIDE) {
         // the hits of primary rays: their shadow rays are coherent too (rt_trace's caller-supplied rays need not be)
-        if (S.packet && A.level == 0 && !A.user_rays) hipLaunchKernelGGL((k_shade_wide<COUNT, GPOW, true>), g, b, 0, st, S, A);
+        if (S.packet && (A.level == 0 || S.packet >= 2) && !A.user_rays) hipLaunchKernelGGL((k_shade_wide<COUNT, GPOW, true>), g, b, 0, st, S, A);
         else hipLaunchKernelGGL((k_shade_wide<COUNT, GPOW, false>), g, b, 0, st, S, A);
     }
     else if (form == RT_FORM_QUAD_FRESH) hipLaunchKernelGGL((k_shade_quad<0, COUNT, GPOW>), g, b, 0, st, S, A);
