@@ -101,9 +101,9 @@ def main():
                     help="rehearsal only: every rank uses GPU 0 (needs --backend gloo)")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="library calls in flight (each in its own scene workspace and stream); 0 = 2, or 1 when one frame is several passes already")
-    ap.add_argument("--frames-per-batch", type=int, default=16,
+    ap.add_argument("--frames-per-batch", type=int, default=32,
                     help="frames (steps) rendered per library call, rt_render_batch_device: every launch then carries "
-                         "that many frames' rays (1..16; 1 = one call per frame)")
+                         "that many frames' rays (1..32; 1 = one call per frame)")
     ap.add_argument("--bvh", default="host", choices=("host", "device"),
                     help="BVH builder: the host's SAH tree (default) or the GPU's linear BVH (RT_SCENE_BVH_DEVICE)")
     ap.add_argument("--watchdog", type=int, default=0, help="dump all Python stacks and exit after this many seconds")
@@ -148,7 +148,7 @@ def main():
     # every launch) and (2) two calls are in flight, each with its own scene workspace, stream and framebuffers. Every
     # frame is still rendered completely and compared with the census frame below.
     # ... as many as fill about one 8 M-sample pass of this rank (a batch of large frames would only add passes)
-    B = max(1, min(16, args.frames_per_batch, (8 << 20) // max(1, (W * H * params.spp) // world)))
+    B = max(1, min(32, args.frames_per_batch, (8 << 20) // max(1, (W * H * params.spp) // world)))
     cams = [cam] * B
     frame_bytes = H * W * 3
 

@@ -163,7 +163,7 @@ int rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_params* par
                      uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
                      uint8_t* d_bgr_out, void* stream, rt_stats* stats);
 
-/* A BATCH of frames in one call: n_frames (1..16) frames of the same size, scene and params that differ only in
+/* A BATCH of frames in one call: n_frames (1..32) frames of the same size, scene and params that differ only in
  * their cameras (an animation's consecutive frames, or the steps of a benchmark). Frame b is written
  * frame_stride_bytes * b behind d_bgr_out. Every launch then works on n_frames times as many rays: a small frame - or
  * one GPU's share of a frame - leaves most of the chip idle in its deep bounce levels and is bound by the host's

@@ -68,7 +68,7 @@ struct FrameParams {
 // A call may render a BATCH of frames that differ only in their cameras: the level-0 samples of frame b follow those
 // of frame b-1, so every launch works on n_frames times as many rays (a small frame, or one rank's share of a frame,
 // leaves most of the chip idle in its deep levels and is bound by the host's launch rate).
-#define RT_MAX_BATCH 16
+#define RT_MAX_BATCH 32
 struct FrameParamsBatch { FrameParams f[RT_MAX_BATCH]; };
 
 #define RT_POW_MAX_INT 64

@@ -12,7 +12,7 @@ base = None
 for n in [int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else "1,2,4,8".split(","))]:
     k = devs[0].lib.rt_tiles_owned(W, H, 32, 32, 0, n)
     stride = k * 32 * 32 * 3
-    for B in (1, 2, 4, 8, 16):
+    for B in (1, 2, 4, 8, 16, 32):
         bufs = [torch.zeros((B * stride,), dtype=torch.uint8, device="cuda") for _ in devs]
         cams = [cam] * B
         def run(calls):
