@@ -374,6 +374,14 @@ def main():
                 "level0_launch_ms": {rocprof_names[k]: ms0[k] / n0[k] for k in range(NK) if n0[k]},
                 "serial_frame_ms": frame_ms / reps, "kernels": per_kernel,
             }
+            # What the launch really moves over HBM (PMC bytes / the same duration). `achieved` follows SURVEY.md 8d to
+            # the letter: every node a RAY visits is priced at 128 B. A packet fetches a node once for its 64 rays,
+            # through the scalar cache, and the trees of this workload live in L2, so `frac` can exceed 1: those bytes
+            # never reach HBM and the HBM roofline does not bind the kernel.
+            tr = traffic.get(rocprof_names[dk])
+            if tr:
+                rate = tr / (avg * 1e-3) / 1e9
+                out["roofline"]["hbm_measured"] = {"achieved": rate, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rate / HBM_PEAK_GBS}
             # the boundary as the reference has it (rt_render: host framebuffer, synchronous): PCIe-inclusive, never `value`
             host_frame = np.zeros((H, W, 3), np.uint8)
             dev.render(cam, params, out=host_frame, want_stats=False)

@@ -1250,8 +1250,17 @@ __device__ __forceinline__ V3 node_color(const DScene& S, const float4* __restri
 
 // Frame parameters by value -> device memory, and the frame's pass counters cleared (one small launch per frame
 // instead of a launch and a memset; see FrameParams).
-__global__ __launch_bounds__(256) void k_set_frame_params(FrameParamsBatch p, uint32_t n_frames, FrameParams* dst, uint4* clear, uint32_t n_clear16) {
-    if (blockIdx.x == 0 && threadIdx.x < n_frames) dst[threadIdx.x] = p.f[threadIdx.x];
+// (At most RT_FP_CHUNK frames per launch, read word by word through the kernel-argument pointer. Measured on the 16-pass
+// frame of config 4, tools/exp_ab.sh: 32 frames by value, indexed with threadIdx = 2.8 KB of arguments that the compiler
+// copies to private scratch: 66.8 ms/frame; 16 frames: 61.3; this form: 57.6 - the launch cost 0.3-0.6 ms per pass.)
+#define RT_FP_CHUNK 8u
+struct FrameParamsChunk { FrameParams f[RT_FP_CHUNK]; };
+static_assert(sizeof(FrameParams) % 4 == 0 && sizeof(FrameParamsChunk) / 4 <= 256, "one word per thread of block 0");
+__global__ __launch_bounds__(256) void k_set_frame_params(FrameParamsChunk p, uint32_t n_frames, FrameParams* dst, uint4* clear, uint32_t n_clear16) {
+    if (blockIdx.x == 0 && threadIdx.x < n_frames * uint32_t(sizeof(FrameParams) / 4)) {
+        const RT_CONSTANT uint32_t* words = (const RT_CONSTANT uint32_t*)__builtin_amdgcn_kernarg_segment_ptr();   // p is the first argument
+        reinterpret_cast<uint32_t*>(dst)[threadIdx.x] = words[threadIdx.x];
+    }
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_clear16; i += gridDim.x * 256) clear[i] = make_uint4(0, 0, 0, 0);
 }
 
@@ -1461,7 +1470,13 @@ void launch_shade(int form, bool count, const DScene& S, const LevelArgs& A, uin
 void launch_set_frame_params(const FrameParamsBatch& p, uint32_t n_frames, FrameParams* dst, void* clear, size_t clear_bytes, hipStream_t st) {
     const uint32_t n16 = uint32_t(clear_bytes / 16);
     const uint32_t grid = n16 ? std::min<uint32_t>((n16 + 255u) / 256u, 1024u) : 1u;
-    hipLaunchKernelGGL(k_set_frame_params, dim3(grid), dim3(256), 0, st, p, n_frames, dst, static_cast<uint4*>(clear), n16);
+    for (uint32_t f0 = 0; f0 < n_frames; f0 += RT_FP_CHUNK) {
+        FrameParamsChunk c;
+        const uint32_t n = std::min(RT_FP_CHUNK, n_frames - f0);
+        for (uint32_t i = 0; i < n; ++i) c.f[i] = p.f[f0 + i];
+        for (uint32_t i = n; i < RT_FP_CHUNK; ++i) c.f[i] = p.f[f0];
+        hipLaunchKernelGGL(k_set_frame_params, dim3(f0 ? 1u : grid), dim3(256), 0, st, c, n, dst + f0, static_cast<uint4*>(clear), f0 ? 0u : n16);
+    }
 }
 void launch_fold(const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st) {
     hipLaunchKernelGGL(k_fold, dim3(grid), dim3(256), 0, st, S, A);
