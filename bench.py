@@ -91,8 +91,8 @@ def cpu_baseline(fs, cam, params, dev, np):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--workload", default="bunny_1080p")
     ap.add_argument("--tile", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -148,16 +148,18 @@ def main():
     # every launch) and (2) two calls are in flight, each with its own scene workspace, stream and framebuffers. Every
     # frame is still rendered completely and compared with the census frame below.
     # ... as many as fill about one 8 M-sample pass of this rank (a batch of large frames would only add passes)
-    B = max(1, min(32, args.frames_per_batch, (8 << 20) // max(1, (W * H * params.spp) // world)))
+    # a frame of several 8 M-sample passes fills the chip by itself: a second call in flight only competes for the caches
+    # (4K 16 spp glass scene: 55 ms one call at a time, 67 ms with two)
+    in_flight = args.frames_in_flight or (1 if (W * H * params.spp) // world >= 2 * (8 << 20) else 2)
+    # ... and at least two calls per slot inside the timed region, so that the exchange of one call (gather, untile)
+    # overlaps the rendering of the next whatever --steps is
+    B = max(1, min(32, args.frames_per_batch, (8 << 20) // max(1, (W * H * params.spp) // world), args.steps // (2 * in_flight)))
     cams = [cam] * B
     frame_bytes = H * W * 3
 
     class Slot:
         pass
     slots = []
-    # a frame of several 8 M-sample passes fills the chip by itself: a second call in flight only competes for the caches
-    # (4K 16 spp glass scene: 55 ms one call at a time, 67 ms with two)
-    in_flight = args.frames_in_flight or (1 if (W * H * params.spp) // world >= 2 * (8 << 20) else 2)
     for k in range(in_flight):
         sl = Slot()
         sl.dev = dev if k == 0 else DeviceScene(fs, device=local, bvh=args.bvh)
