@@ -1,6 +1,6 @@
 # one bench line per workload (no CPU baseline), plus the 2-rank gloo rehearsal of the default workload on one GPU
 for w in c1_scene_yaml_800x600 c2_analytic_1080p_4spp c3_bunny_1080p_shadows bunny_1080p c4_bunny_glass_4k_16spp c5_field_10m_1080p_4spp; do
-  timeout -k 10 300 python bench.py --no-cpu-baseline --workload $w --steps ${STEPS:-32} --warmup 8 > gpurun_out/w_$w.json 2> gpurun_out/w_$w.err || { echo "FAILED $w"; tail -5 gpurun_out/w_$w.err; exit 1; }
+  timeout -k 10 300 python bench.py --no-cpu-baseline --workload $w --steps ${STEPS:-128} --warmup ${WARMUP:-32} > gpurun_out/w_$w.json 2> gpurun_out/w_$w.err || { echo "FAILED $w"; tail -5 gpurun_out/w_$w.err; exit 1; }
   python3 -c "
 import json; d=json.load(open('gpurun_out/w_$w.json')); print('$w', round(d['ms_per_frame'],3), 'ms', round(d['value']), 'Mrays/s', d['config']['rays_per_frame'], 'rays', d['config']['level_rays'][:6])"
 done
