@@ -106,6 +106,9 @@ def main():
                          "that many frames' rays (1..32; 1 = one call per frame)")
     ap.add_argument("--bvh", default="host", choices=("host", "device"),
                     help="BVH builder: the host's SAH tree (default) or the GPU's linear BVH (RT_SCENE_BVH_DEVICE)")
+    ap.add_argument("--rehearse-exchange", action="store_true",
+                    help="rehearsal only: a 1-rank job (launched through torch.distributed.run) takes the N-rank path - tiles, "
+                         "RCCL gather to itself, untile - so that the exchange code runs on the real backend with one GPU")
     ap.add_argument("--watchdog", type=int, default=0, help="dump all Python stacks and exit after this many seconds")
     args = ap.parse_args()
     if args.watchdog:
@@ -128,7 +131,8 @@ def main():
     if args.single_device:
         local = 0
     torch.cuda.set_device(local)
-    if world > 1:
+    multi = world > 1 or args.rehearse_exchange        # the N-rank code path
+    if multi:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
@@ -168,7 +172,7 @@ def main():
         sl.frames = torch.zeros((B, H, W, 3), dtype=torch.uint8, device="cuda")
         sl.frame = sl.frames[0]
         sl.last_b = 0
-        if world > 1:
+        if multi:
             sl.n_slot = lib.rt_tiles_owned(W, H, tw, th, 0, world)       # part 0 owns the most tiles
             sl.part_bytes = sl.n_slot * tw * th * 3                       # one frame's tiles of one part
             sl.mine = torch.zeros((B * sl.part_bytes,), dtype=torch.uint8, device="cuda")
@@ -196,7 +200,7 @@ def main():
         sl.last_b = b
         h = sl.stream.cuda_stream
         with torch.cuda.stream(sl.stream):
-            if world == 1:
+            if not multi:
                 sl.dev.render_batch_device(cams[:b], params, sl.frames.data_ptr(), frame_bytes, stream=h)
                 return
             sl.dev.render_tiles_batch_device(cams[:b], params, (tw, th), rank, world, sl.mine.data_ptr(), sl.part_bytes, stream=h)
@@ -224,7 +228,7 @@ def main():
             call += 1
 
     def sync():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -236,7 +240,7 @@ def main():
                 sl.dev.status()
             except cabi.RtError:
                 bad = 1
-        if world > 1:
+        if multi:
             f = torch.tensor([bad], dtype=torch.int32, device="cuda" if args.backend == "nccl" else "cpu")
             dist.all_reduce(f, op=dist.ReduceOp.MAX)
             bad = int(f.item())
@@ -256,7 +260,7 @@ def main():
     elapsed = time.perf_counter() - t
     if overflowed():
         raise SystemExit("bench.py: a timed frame ran out of ray pool; the measurement is void")
-    if world > 1:
+    if multi:
         e = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(e, op=dist.ReduceOp.MAX)
         elapsed = float(e.item())
@@ -283,7 +287,7 @@ def main():
         out["config"]["frames_in_flight"] = len(slots)
         out["config"]["frames_per_batch"] = B
         out["config"]["pool_adapt_rounds"] = adapt_rounds
-        if world == 1 and (len(slots) > 1 or B > 1):
+        if not multi and (len(slots) > 1 or B > 1):
             # latency view: the same frames one at a time (one workspace, one stream)
             t = time.perf_counter()
             for _ in range(args.steps):
@@ -291,7 +295,7 @@ def main():
                     dev.render_device(cam, params, frame.data_ptr(), stream=stream)
             torch.cuda.synchronize()
             out["one_frame_at_a_time"] = {"ms_per_frame": (time.perf_counter() - t) / args.steps * 1e3}
-        if world == 1:
+        if not multi:
             # The frame's time is in four kernels: k_extend_wide / k_extend_quad (closest hits: analytic objects one ray
             # per lane, meshes one ray per quad) and k_shade_wide / k_shade_quad (shadow rays + Phong). A call with stats
             # runs them back to back on ONE stream with HIP events around every launch (the untimed path overlaps the
@@ -396,7 +400,7 @@ def main():
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(fs, cam, params, dev, np)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -331,22 +331,28 @@ __device__ __forceinline__ void packet_traverse(const DScene& S, uint32_t root, 
     int stack = 0;                          // lane k = stack entry k
     const uint32_t lane = lane_id();
     uint32_t sp = 0;
-    uint32_t cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)(__ballot(have) ? root : RT_DONE));   // RT_NO_CHILD == RT_DONE
+    uint32_t cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_ballot_w64(have) ? root : RT_DONE));   // RT_NO_CHILD == RT_DONE
     while (cur != RT_DONE) {
         if (!(cur & RT_LEAF_BIT)) {
             const RT_CONSTANT u32x4* np = (const RT_CONSTANT u32x4*)(const void*)(S.nodes) + 8u * (size_t)cur;
             if (COUNT) { wk.nodes += live; wk.wave_nodes += wave_once(); }
             const float cull = ANY ? best : best * 1.000001f;
             uint32_t key[4], ref[4];
+            // the whole node is requested at once (scalar loads return in any order, so the only wait there is is for
+            // all of them: four requests one after the other would be four latencies), and nothing below branches
+            u32x4 nd[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) nd[c] = np[c];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const float4 a = as_f4(np[c]), b = as_f4(np[4 + c]);
+                const float4 a = as_f4(nd[c]), b = as_f4(nd[4 + c]);
                 ref[c] = __float_as_uint(a.w);
                 bool h;
                 const float tn = slab(a.x, a.y, a.z, b.x, b.y, b.z, inv, ood, cull, h);
-                const unsigned long long m = __ballot(h && live && ref[c] != RT_NO_CHILD);
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(h && live && ref[c] != RT_NO_CHILD);
                 // distance of the first ray that hits the child (tn >= 0: its bits order like its value); none: last
-                key[c] = m ? (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(tn), __ffsll((long long)m) - 1) : 0xFFFFFFFFu;
+                const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(tn), (__ffsll((long long)m) - 1) & 63);
+                key[c] = m ? first : 0xFFFFFFFFu;
             }
             // sort the four (key, ref) pairs, all wave-uniform: 5 compare-exchanges
 #define RT_CSWAP(i, j) { const bool sw = key[j] < key[i]; const uint32_t k0_ = sw ? key[j] : key[i], k1_ = sw ? key[i] : key[j]; \
@@ -364,10 +370,14 @@ __device__ __forceinline__ void packet_traverse(const DScene& S, uint32_t root, 
             const uint32_t cnt = ((cur >> 27) & 15u) + 1u;
             const RT_CONSTANT u32x4* lp = (const RT_CONSTANT u32x4*)(const void*)(S.leaves) + 12u * (size_t)(cur & RT_LEAF_START_MASK);
             if (COUNT) { wk.tris += live ? cnt : 0u; wk.wave_tris += wave_once(); }
+            // the whole block (192 B, always allocated in full) in one go, as for a node
+            u32x4 lf[12];
+#pragma unroll
+            for (int c = 0; c < 12; ++c) lf[c] = lp[c];
 #pragma unroll
             for (uint32_t t = 0; t < RT_MAX_LEAF_TRIS; ++t) {
                 if (t < cnt) {                                                                   // wave-uniform
-                    const float4 q0 = as_f4(lp[t]), q1 = as_f4(lp[4 + t]), q2 = as_f4(lp[8 + t]);
+                    const float4 q0 = as_f4(lf[t]), q1 = as_f4(lf[4 + t]), q2 = as_f4(lf[8 + t]);
                     float tt, u, v;
                     if (live && tri_isect(f4xyz(q0), f4xyz(q1), f4xyz(q2), ray, tt, u, v)) {
                         const uint32_t f = __float_as_uint(q0.w);
@@ -379,7 +389,7 @@ __device__ __forceinline__ void packet_traverse(const DScene& S, uint32_t root, 
                     }
                 }
             }
-            if (ANY && __ballot(live) == 0) cur = RT_DONE;
+            if (ANY && __builtin_amdgcn_ballot_w64(live) == 0) cur = RT_DONE;
             else if (sp) { --sp; cur = (uint32_t)__builtin_amdgcn_readlane(stack, (int)sp); }
             else cur = RT_DONE;
         }
