@@ -283,7 +283,7 @@ extern "C" int rt_scene_create_ex(const rt_flat_scene* sc, int device, uint32_t 
 
     if (hipMalloc(reinterpret_cast<void**>(&s->d_counters), sizeof(PassCounters) * RT_MAX_PASSES) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&s->h_counters), sizeof(PassCounters) * RT_MAX_PASSES) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void**>(&s->h_hint), sizeof(ShardCounters) * RT_SHARDS) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&s->h_hint), sizeof(ShardCounters) * RT_SHARDS * RT_MAX_PASSES) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&s->h_overflow), 64) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&s->d_fp), sizeof(FrameParams) * RT_MAX_BATCH) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&s->d_aa), sizeof(float) * 2 * (RT_MAX_AA_POINTS + 1)) != hipSuccess ||
@@ -292,9 +292,10 @@ extern "C" int rt_scene_create_ex(const rt_flat_scene* sc, int device, uint32_t 
         free_scene(s);
         return RT_ERR_DEVICE;
     }
-    std::memset(s->h_hint, 0, sizeof(ShardCounters) * RT_SHARDS);
+    std::memset(s->h_hint, 0, sizeof(ShardCounters) * RT_SHARDS * RT_MAX_PASSES);
     *s->h_overflow = 0;
-    for (int i = 0; i < RT_MAX_LEVELS + 4; ++i) s->h_hint[0].level[i] = 0xFFFFFFFFu;   // unknown: assume large levels
+    for (int p = 0; p < RT_MAX_PASSES; ++p)
+        for (int i = 0; i < RT_MAX_LEVELS + 4; ++i) s->h_hint[size_t(p) * RT_SHARDS].level[i] = 0xFFFFFFFFu;   // unknown: assume large levels
     *out = s;
     return RT_OK;
 }
@@ -468,18 +469,42 @@ static int timed_launch(FrameJob& J, hipStream_t st, uint8_t kind, F&& launch) {
     return RT_OK;
 }
 
-// Is a level (or range) expected to hold enough rays to fill the chip one per lane? Sizes come from the previous
-// pass of this scene (h_hint); unknown = large.
-static uint64_t level_hint(const rt_scene* s, int l) {
+// Is a level (or range) expected to hold enough rays to fill the chip one per lane? Sizes come from the pass with the
+// same ordinal of the scene's previous frame (h_hint: the passes of a frame differ - the floor at the bottom of the
+// picture bounces nothing, the glass in the middle a lot - but pass k of the next frame looks like pass k of this
+// one); unknown = large.
+static uint64_t level_hint(const rt_scene* s, uint32_t pass, int l) {
     uint64_t n = 0;
-    for (uint32_t k = 0; k < RT_SHARDS; ++k) n += s->h_hint[k].level[l];
+    const ShardCounters* h = s->h_hint + size_t(pass) * RT_SHARDS;
+    for (uint32_t k = 0; k < RT_SHARDS; ++k) n += h[k].level[l];
     return n;
 }
-static bool expect_large(const rt_scene* s, int lo, int hi) {
+static bool expect_large(const rt_scene* s, uint32_t pass, int lo, int hi) {
     if (lo == 0) return true;
+    // Measured (tools/exp_thr.sh): with level 0 traversed as packets, the bounce levels are fastest as ONE quad launch
+    // per level whatever their size (bunny_1080p 0.389 -> 0.362 ms, 10 M-triangle field at 1080p 6.04 -> 5.48 ms); where
+    // the deeper levels use packets too (16+ spp) a level pays for the per-lane kernels from about a million rays on
+    // (field at 8K 64 spp: threshold 131 k 829 ms, 1 M 727 ms, 4 M 818 ms; 4K glass scene flat up to 1 M, 73 ms at 4 M).
+    const char* e = std::getenv("RT_LARGE_THR");      // experiments and tests
+    const uint64_t thr = e ? uint64_t(std::atoll(e)) : s->d.packet >= 2 ? (1u << 20) : s->d.packet == 1 ? ~0ull : 16u * RT_LEVEL_GRID;
     for (int l = lo; l <= hi; ++l)
-        if (level_hint(s, l) > 16u * RT_LEVEL_GRID) return true;
+        if (level_hint(s, pass, l) > thr) return true;
     return false;
+}
+
+// Workgroups for a quad launch over the small levels lo..hi. The kernels spread a level's rays over at most 4096 waves
+// (quads_per_wave: as few rays per wave as that allows, the launch is latency-bound) and deal the groups to workgroups
+// in rounds of 2048 (group_of: runs of 8 per CU), so the launch needs the expected groups rounded up to 2048 and no
+// more: a workgroup that finds nothing to do still costs ~280 instructions (shard view, group scan), and 9 x 8192 of
+// them were 9 % of a 1080p frame's instructions. Expected = the count of the previous frame's pass plus a quarter; the
+// kernels stride over the device-side count, so a short hint costs time, never rays.
+static uint32_t small_grid(const rt_scene* s, uint32_t pass, int lo, int hi) {
+    uint64_t n = 0;
+    for (int l = lo; l <= hi; ++l) n += level_hint(s, pass, l);
+    const uint64_t cap = RT_LEVEL_GRID;       // (16 k and 32 k measured the same, 64 k slower)
+    const uint64_t want = n + n / 4u + 2u * RT_SHARDS;
+    const uint64_t groups = std::max<uint64_t>(std::min<uint64_t>(4096u + 2u * RT_SHARDS, want), want / 16u);
+    return uint32_t(std::min<uint64_t>(cap, (groups + 2047u) / 2048u * 2048u));
 }
 
 // Enqueue the passes covering pixels [px0, px0+npx) of the frame's pixel order, pass_px pixels at a time.
@@ -557,7 +582,7 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
                 B.level = part == 0 ? 0 : (lo == 0 && hi > 0 ? 1 : lo);
                 B.level_hi = part == 0 ? 0 : hi;
                 const uint32_t g = form == RT_FORM_WIDE ? (B.level_hi == 0 ? grid0 : RT_LEVEL_GRID)
-                                   : (B.level_hi == 0 ? grid0q : (form == RT_FORM_QUAD_FRESH ? RT_LEVEL_GRID : 4u * RT_LEVEL_GRID));
+                                   : (B.level_hi == 0 ? grid0q : (form == RT_FORM_QUAD_FRESH ? small_grid(s, slot, B.level, B.level_hi) : 4u * RT_LEVEL_GRID));
                 const int rc2 = timed_launch(J, sb, form == RT_FORM_WIDE ? RT_K_SHADE_WIDE : form == RT_FORM_QUAD_PARKED ? RT_K_SHADE_PARKED : RT_K_SHADE_QUAD,
                                              [&] { launch_shade(form, s->count_work, s->d, B, g, sb); });
                 if (rc2 != RT_OK) return rc2;
@@ -569,7 +594,7 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
             LevelArgs B = A;
             B.level = lv; B.level_hi = lv;
             const int src = lv == 0 ? 0 : 1;
-            const bool large = !meshes || ((J.large_mask >> lv) & 1u);
+            const bool large = !meshes || lv == 0 || expect_large(s, slot, lv, lv);
             if (large) {
                 if (small_lo >= 0) {     // shade the small levels before this one
                     if (overlap) HIP_TRY(hipEventRecord(s->ev_sync[2 * lv], sa));
@@ -593,7 +618,7 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
                 }
             } else {
                 B.wave_log = (lv == log_level) ? wave_log : nullptr;
-                if ((rc = timed_launch(J, sa, RT_K_EXTEND_QUAD, [&] { launch_extend(src, RT_FORM_QUAD_FRESH, s->count_work, s->d, B, RT_LEVEL_GRID, sa); })) != RT_OK) return rc;
+                if ((rc = timed_launch(J, sa, RT_K_EXTEND_QUAD, [&] { launch_extend(src, RT_FORM_QUAD_FRESH, s->count_work, s->d, B, small_grid(s, slot, lv, lv), sa); })) != RT_OK) return rc;
                 if (small_lo < 0) small_lo = lv;
                 if (lv - small_lo + 1 >= 3 && lv < levels) {     // shade a run of three small levels while the deeper ones are traced
                     if (overlap) HIP_TRY(hipEventRecord(s->ev_sync[2 * lv + 1], sa));
@@ -630,7 +655,7 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
         launch_resolve(s->d, A, J.d_out, sa);
         HIP_TRY(hipGetLastError());
         // level sizes of this pass -> scheduling hint of the next one (no sync; see h_hint)
-        HIP_TRY(hipMemcpyAsync(s->h_hint, pc->sc, sizeof(ShardCounters) * RT_SHARDS, hipMemcpyDeviceToHost, sa));
+        HIP_TRY(hipMemcpyAsync(s->h_hint + size_t(slot) * RT_SHARDS, pc->sc, sizeof(ShardCounters) * RT_SHARDS, hipMemcpyDeviceToHost, sa));
         recs.push_back({px0 + done, cnt, slot});
     }
     return RT_OK;
@@ -684,7 +709,7 @@ static int render_frame(rt_scene* s, const rt_camera* cam, uint32_t n_frames, co
     B.frame_samples = n_frames > 1 ? uint32_t(frame_px * spp) : 0u;
     B.out_stride = out_stride;
     for (int lv = 0; lv <= prm->max_depth; ++lv)
-        if (expect_large(s, lv, lv)) J.large_mask |= 1u << lv;
+        if (expect_large(s, 0, lv, lv)) J.large_mask |= 1u << lv;      // (key of the opt-in graph cache only)
 
     const uint64_t n_pass = (total_px + pass_px - 1) / pass_px;
     if (n_pass > RT_MAX_PASSES) { rt_set_error("frame needs %llu passes (max %d)", (unsigned long long)n_pass, RT_MAX_PASSES); return RT_ERR_LIMIT; }
