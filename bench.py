@@ -388,6 +388,15 @@ def main():
             if tr:
                 rate = tr / (avg * 1e-3) / 1e9
                 out["roofline"]["hbm_measured"] = {"achieved": rate, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rate / HBM_PEAK_GBS}
+            # What does bind the frame: VALU issue. SQ_INSTS_VALU of all launches of one frame (PMC pass committed under
+            # profiles/, tools/exp_pmc_sq.sh) x 4 cycles per wave64 instruction / (1024 SIMDs x 2.4 GHz), against the
+            # measured time per frame.
+            pf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_sq_{args.workload}.json")))
+            if pf:
+                n_valu = json.load(open(pf[-1]))["valu_instructions_per_frame"]
+                busy_ms = n_valu * 4 / (1024 * 2.4e9) * 1e3
+                out["roofline"]["valu_issue"] = {"valu_instructions_per_frame": n_valu, "cycles_per_instruction": 4, "simds": 1024,
+                                                 "clock_GHz": 2.4, "busy_ms_per_frame": busy_ms, "frac": busy_ms / ms}
             # the boundary as the reference has it (rt_render: host framebuffer, synchronous): PCIe-inclusive, never `value`
             host_frame = np.zeros((H, W, 3), np.uint8)
             dev.render(cam, params, out=host_frame, want_stats=False)
