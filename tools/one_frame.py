@@ -1,4 +1,6 @@
-"""Renders a few frames of a workload (async path, no stats) - a small target for rocprofv3 counter passes."""
+"""Renders a few frames of a workload - a small target for rocprofv3 passes. Default: the asynchronous multi-stream path;
+third argument "serial": calls with statistics, i.e. every launch alone on one stream between HIP events (what bench.py's
+roofline durations are measured on), so that rocprofv3's per-kernel averages can be held against them."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,6 +11,21 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 fs, cam, p = wl.make_workload(name)
 dev = DeviceScene(fs)
 frame = torch.zeros((cam.imHeight, cam.imWidth, 3), dtype=torch.uint8, device="cuda")
-for _ in range(n):
-    dev.render_device(cam, p, frame.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+serial = len(sys.argv) > 3 and sys.argv[3] == "serial"
+if serial:
+    from raytracer_amd.cabi import rt_stats
+    ms, cnt = [0.0] * 5, [0] * 5
+    for k in range(n + 2):
+        st = rt_stats()
+        dev.render_device(cam, p, frame.data_ptr(), stream=torch.cuda.current_stream().cuda_stream, stats=st)
+        if k >= 2:       # the first frames of a scene do not know their level sizes yet
+            for j in range(5):
+                ms[j] += st.kernel_ms_by[j]; cnt[j] += st.kernel_launches_by[j]
+    names = ("k_extend_wide", "k_shade_wide", "k_extend_quad", "k_shade_quad<0|1>", "k_shade_quad<2>")
+    for j in range(5):
+        if cnt[j]:
+            print(f"HIP events: {names[j]}: {cnt[j]} launches, average {ms[j] / cnt[j] * 1e3:.1f} us")
+else:
+    for _ in range(n):
+        dev.render_device(cam, p, frame.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
 torch.cuda.synchronize()
