@@ -396,7 +396,7 @@ def main():
                 n_valu = json.load(open(pf[-1]))["valu_instructions_per_frame"]
                 busy_ms = n_valu * 4 / (1024 * 2.4e9) * 1e3
                 out["roofline"]["valu_issue"] = {"valu_instructions_per_frame": n_valu, "cycles_per_instruction": 4, "simds": 1024,
-                                                 "clock_GHz": 2.4, "busy_ms_per_frame": busy_ms, "frac": busy_ms / ms}
+                                                 "clock_GHz": 2.4, "busy_ms_per_frame": busy_ms, "frac": busy_ms / out["ms_per_step"]}
             # the boundary as the reference has it (rt_render: host framebuffer, synchronous): PCIe-inclusive, never `value`
             host_frame = np.zeros((H, W, 3), np.uint8)
             dev.render(cam, params, out=host_frame, want_stats=False)
