@@ -507,6 +507,18 @@ static uint32_t small_grid(const rt_scene* s, uint32_t pass, int lo, int hi) {
     return uint32_t(std::min<uint64_t>(cap, (groups + 2047u) / 2048u * 2048u));
 }
 
+// Workgroups for the quad launch that resumes what k_shade_wide queued at level `lv` (queue_s): sized like small_grid
+// from the queue length the same pass of the previous frame reached; unknown = the full grid.
+static uint32_t resume_grid(const rt_scene* s, uint32_t pass, int lv) {
+    const ShardCounters* h = s->h_hint + size_t(pass) * RT_SHARDS;
+    if (h[0].level[lv] == 0xFFFFFFFFu) return 4u * RT_LEVEL_GRID;
+    uint64_t n = 0;
+    for (uint32_t k = 0; k < RT_SHARDS; ++k) n += h[k].qs[lv];
+    const uint64_t want = n + n / 4u + 2u * RT_SHARDS;
+    const uint64_t groups = std::max<uint64_t>(std::min<uint64_t>(4096u + 2u * RT_SHARDS, want), want / 16u);
+    return uint32_t(std::min<uint64_t>(4u * RT_LEVEL_GRID, (groups + 2047u) / 2048u * 2048u));
+}
+
 // Enqueue the passes covering pixels [px0, px0+npx) of the frame's pixel order, pass_px pixels at a time.
 // Records which PassCounters slot each pass used in `slots` (px0, npx, slot).
 //
@@ -568,8 +580,8 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
             }
         }
         // shade launch `form` over levels lo..hi on the level's shade stream, after event `after` of stream A
-        auto shade = [&](int form, int lo, int hi, int after) -> int {
-            const int which = (form == RT_FORM_QUAD_FRESH ? 2 : (lo & 1)) % s->n_shade_streams;
+        auto shade = [&](int form, int lo, int hi, int after, bool small_run = false) -> int {
+            const int which = ((form == RT_FORM_QUAD_FRESH || small_run) ? 2 : (lo & 1)) % s->n_shade_streams;
             hipStream_t sb = overlap ? s->shade_stream[which] : sa;
             if (overlap) {
                 if (last_wait[which] != after) HIP_TRY(hipStreamWaitEvent(sb, s->ev_sync[after], 0));
@@ -581,13 +593,30 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
                 LevelArgs B = A;
                 B.level = part == 0 ? 0 : (lo == 0 && hi > 0 ? 1 : lo);
                 B.level_hi = part == 0 ? 0 : hi;
-                const uint32_t g = form == RT_FORM_WIDE ? (B.level_hi == 0 ? grid0 : RT_LEVEL_GRID)
-                                   : (B.level_hi == 0 ? grid0q : (form == RT_FORM_QUAD_FRESH ? small_grid(s, slot, B.level, B.level_hi) : 4u * RT_LEVEL_GRID));
+                uint32_t wide_grid = RT_LEVEL_GRID;
+                if (small_run && form == RT_FORM_WIDE) {      // one workgroup per 64 entries expected (plus a quarter, plus the shards' ragged ends)
+                    uint64_t n = 0;
+                    for (int l = B.level; l <= B.level_hi; ++l) n += level_hint(s, slot, l);
+                    wide_grid = uint32_t(std::min<uint64_t>(RT_LEVEL_GRID, (n + n / 4u) / 64u + 2u * RT_SHARDS));
+                }
+                const uint32_t g = form == RT_FORM_WIDE ? (B.level_hi == 0 ? grid0 : wide_grid)
+                                   : (B.level_hi == 0 ? grid0q : (form == RT_FORM_QUAD_FRESH ? small_grid(s, slot, B.level, B.level_hi)
+                                                                  : small_run ? resume_grid(s, slot, B.level) : 4u * RT_LEVEL_GRID));
                 const int rc2 = timed_launch(J, sb, form == RT_FORM_WIDE ? RT_K_SHADE_WIDE : form == RT_FORM_QUAD_PARKED ? RT_K_SHADE_PARKED : RT_K_SHADE_QUAD,
                                              [&] { launch_shade(form, s->count_work, s->d, B, g, sb); });
                 if (rc2 != RT_OK) return rc2;
             }
             return RT_OK;
+        };
+        // The hits of a run of small levels lo..hi (extended as whole rays by the quad kernel): the light loops' analytic
+        // objects and the Phong terms one hit per LANE (a quad kernel computes them four times over), the shadow rays that
+        // reach a mesh queued and resumed by quads: 38 M -> see DESIGN.md 4 VALU instructions per 1080p frame.
+        static const bool split_small = std::getenv("RT_SPLIT_SMALL") ? std::atoi(std::getenv("RT_SPLIT_SMALL")) != 0 : true;
+        auto shade_small = [&](int lo, int hi, int after) -> int {
+            if (!split_small) return shade(RT_FORM_QUAD_FRESH, lo, hi, after);
+            const int rc2 = shade(RT_FORM_WIDE, lo, hi, after, true);
+            if (rc2 != RT_OK) return rc2;
+            return shade(RT_FORM_QUAD_RESUME, lo, hi, after, true);
         };
         int small_lo = -1;      // first level of the run of small levels not shaded yet
         for (int lv = 0; lv <= levels; ++lv) {
@@ -598,7 +627,7 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
             if (large) {
                 if (small_lo >= 0) {     // shade the small levels before this one
                     if (overlap) HIP_TRY(hipEventRecord(s->ev_sync[2 * lv], sa));
-                    if ((rc = shade(RT_FORM_QUAD_FRESH, small_lo, lv - 1, 2 * lv)) != RT_OK) return rc;
+                    if ((rc = shade_small(small_lo, lv - 1, 2 * lv)) != RT_OK) return rc;
                     small_lo = -1;
                 }
                 if ((rc = timed_launch(J, sa, RT_K_EXTEND_WIDE, [&] { launch_extend(src, RT_FORM_WIDE, s->count_work, s->d, B, lv == 0 ? grid0 : RT_LEVEL_GRID, sa); })) != RT_OK) return rc;
@@ -622,7 +651,7 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
                 if (small_lo < 0) small_lo = lv;
                 if (lv - small_lo + 1 >= 3 && lv < levels) {     // shade a run of three small levels while the deeper ones are traced
                     if (overlap) HIP_TRY(hipEventRecord(s->ev_sync[2 * lv + 1], sa));
-                    if ((rc = shade(RT_FORM_QUAD_FRESH, small_lo, lv, 2 * lv + 1)) != RT_OK) return rc;
+                    if ((rc = shade_small(small_lo, lv, 2 * lv + 1)) != RT_OK) return rc;
                     small_lo = -1;
                 }
             }
@@ -637,7 +666,7 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
         if (small_lo >= 0) {
             const int ev = 2 * RT_MAX_LEVELS;
             if (overlap) HIP_TRY(hipEventRecord(s->ev_sync[ev], sa));
-            if ((rc = shade(RT_FORM_QUAD_FRESH, small_lo, levels, ev)) != RT_OK) return rc;
+            if ((rc = shade_small(small_lo, levels, ev)) != RT_OK) return rc;
         }
         for (int k = 0; k < 3; ++k)
             if (used_shade[k]) {
