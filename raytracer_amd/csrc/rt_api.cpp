@@ -612,7 +612,7 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
         };
         // The hits of a run of small levels lo..hi (extended as whole rays by the quad kernel): the light loops' analytic
         // objects and the Phong terms one hit per LANE (a quad kernel computes them four times over), the shadow rays that
-        // reach a mesh queued and resumed by quads: 38 M -> see DESIGN.md 4 VALU instructions per 1080p frame.
+        // reach a mesh queued and resumed by quads: 39 M -> 23 M VALU instructions per 1080p frame.
         static const bool split_small = std::getenv("RT_SPLIT_SMALL") ? std::atoi(std::getenv("RT_SPLIT_SMALL")) != 0 : true;
         auto shade_small = [&](int lo, int hi, int after) -> int {
             // (not where the per-lane kernels traverse meshes as packets at every level: the rays of a small bounce level
