@@ -600,8 +600,9 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
                 LevelArgs B = A;
                 B.level = part == 0 ? 0 : (lo == 0 && hi > 0 ? 1 : lo);
                 B.level_hi = part == 0 ? 0 : hi;
-                const uint32_t wide_grid = (small_run && form == RT_FORM_WIDE) ? wide_grid_for(s, slot, B.level, B.level_hi) : RT_LEVEL_GRID;
-                const uint32_t g = form == RT_FORM_WIDE ? (B.level_hi == 0 ? grid0 : wide_grid)
+                const bool wide = form == RT_FORM_WIDE || form == RT_FORM_WIDE_SERVE;
+                const uint32_t wide_grid = (small_run && wide) ? wide_grid_for(s, slot, B.level, B.level_hi) : RT_LEVEL_GRID;
+                const uint32_t g = wide ? (B.level_hi == 0 ? grid0 : wide_grid)
                                    : (B.level_hi == 0 ? grid0q : (form == RT_FORM_QUAD_FRESH ? small_grid(s, slot, B.level, B.level_hi)
                                                                   : small_run ? resume_grid(s, slot, B.level) : 4u * RT_LEVEL_GRID));
                 const int rc2 = timed_launch(J, sb, form == RT_FORM_WIDE ? RT_K_SHADE_WIDE : form == RT_FORM_QUAD_PARKED ? RT_K_SHADE_PARKED : RT_K_SHADE_QUAD,
@@ -613,11 +614,19 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
         // The hits of a run of small levels lo..hi (extended as whole rays by the quad kernel): the light loops' analytic
         // objects and the Phong terms one hit per LANE (a quad kernel computes them four times over), the shadow rays that
         // reach a mesh queued and resumed by quads: 39 M -> 23 M VALU instructions per 1080p frame.
-        static const bool split_small = std::getenv("RT_SPLIT_SMALL") ? std::atoi(std::getenv("RT_SPLIT_SMALL")) != 0 : true;
+        // Bounce levels of a pass that fills the chip by itself (4 M samples and more: a batch of frames, a 4K frame) are
+        // bound by instruction issue, not by the length of their waves: there the per-lane kernels with quad service do
+        // extend and shade (fewest instructions: bunny_1080p in batches 0.326 -> 0.302 ms, c1 0.089 -> 0.080, 10 M-triangle
+        // field 5.40 -> 5.22); a smaller pass keeps one ray per quad, whose waves are a quarter as long (one 1080p frame at
+        // a time: 0.73 ms against 0.91 with quad service). RT_SERVE=0/1 overrides.
+        const int serve_env = std::getenv("RT_SERVE") ? std::atoi(std::getenv("RT_SERVE")) : -1;
+        const bool serve = s->d.packet == 1 && (serve_env >= 0 ? serve_env != 0 : A.n0 >= (4u << 20));
+        const bool split_small = std::getenv("RT_SPLIT_SMALL") ? std::atoi(std::getenv("RT_SPLIT_SMALL")) != 0 : true;
         auto shade_small = [&](int lo, int hi, int after) -> int {
             // (not where the per-lane kernels traverse meshes as packets at every level: the rays of a small bounce level
             // have nothing in common - 10 M-triangle field at 8K 64 spp 717 -> 970 ms)
             if (!split_small || s->d.packet >= 2) return shade(RT_FORM_QUAD_FRESH, lo, hi, after);
+            if (serve && level_hint(s, slot, lo) < 0xFFFFFFFFull) return shade(RT_FORM_WIDE_SERVE, lo, hi, after, true);
             const int rc2 = shade(RT_FORM_WIDE, lo, hi, after, true);
             if (rc2 != RT_OK) return rc2;
             return shade(RT_FORM_QUAD_RESUME, lo, hi, after, true);
@@ -654,6 +663,10 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
                 // (the same split for the extend side - per-lane kernel, queue, resuming quads, launches sized by the hints -
                 // was measured slower at every level size: bunny_1080p 0.325 -> 0.345 ms, 10 M-triangle field 5.40 -> 5.67..5.86:
                 // most bounce rays reach the mesh anyway, and their state makes a round trip through memory)
+                const uint64_t lh = level_hint(s, slot, lv);
+                if (serve && lh < 0xFFFFFFFFull) {
+                    if ((rc = timed_launch(J, sa, RT_K_EXTEND_QUAD, [&] { launch_extend(src, RT_FORM_WIDE_SERVE, s->count_work, s->d, B, wide_grid_for(s, slot, lv, lv), sa); })) != RT_OK) return rc;
+                } else
                 if ((rc = timed_launch(J, sa, RT_K_EXTEND_QUAD, [&] { launch_extend(src, RT_FORM_QUAD_FRESH, s->count_work, s->d, B, small_grid(s, slot, lv, lv), sa); })) != RT_OK) return rc;
                 if (small_lo < 0) small_lo = lv;
                 if (lv - small_lo + 1 >= 3 && lv < levels) {     // shade a run of three small levels while the deeper ones are traced

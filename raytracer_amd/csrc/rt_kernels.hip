@@ -397,6 +397,41 @@ __device__ __forceinline__ void packet_traverse(const DScene& S, uint32_t root, 
     out.t = best; out.u = bu; out.v = bv; out.face = face;
 }
 
+// ---- quad service: a per-lane kernel whose rays reach a mesh traverses it with its own quads ---------------------
+// The lanes that need the traversal (`need`) are served 16 at a time: quad q takes over the ray of the q-th needing
+// lane (10 cross-lane moves in, 4 out), the wave runs quad_traverse, the results go back to the lanes they belong
+// to. Everything else of the ray - analytic objects, Fresnel, Phong - stays one ray per lane, where a quad kernel
+// computes it four times over. For the bounce levels, whose rays have nothing in common (no packets) and mostly do
+// reach the mesh (so queueing them, which costs a round trip of their state through memory, does not pay).
+// `lds` = the wave's 16-column stack (RT_QSTACK x 16 words). Called with all 64 lanes active; same results as
+// quad_traverse on each ray.
+__device__ __forceinline__ uint32_t select_bit(unsigned long long mask, uint32_t q);      // index of the q-th set bit (below)
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ void serve_traverse(const DScene& S, uint32_t root, bool need, const Ray& ray, float tmax,
+                                               QuadHit& out, uint32_t* lds, Work& wk) {
+    const uint32_t lane = lane_id(), quad = lane >> 2;
+    out.face = 0xFFFFFFFFu; out.t = 0; out.u = 0; out.v = 0;
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(need);
+    const uint32_t n = (uint32_t)__popcll(m);                                        // wave-uniform
+    const uint32_t my_rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));        // among the needing lanes
+    for (uint32_t base = 0; base < n; base += 16u) {
+        const uint32_t want = base + quad;
+        const bool have = want < n;
+        const int src = (int)(have ? select_bit(m, want) : lane);
+        Ray qr;
+        qr.o = mk(__shfl(ray.o.x, src), __shfl(ray.o.y, src), __shfl(ray.o.z, src));
+        qr.d = mk(__shfl(ray.d.x, src), __shfl(ray.d.y, src), __shfl(ray.d.z, src));
+        const float qt = ANY ? __shfl(tmax, src) : FLT_MAX;
+        QuadHit q;
+        q.face = 0xFFFFFFFFu; q.t = 0; q.u = 0; q.v = 0;
+        quad_traverse<ANY, COUNT>(S, root, have, qr, qt, q, lds + quad, wk);
+        const int from = (int)(((my_rank - base) & 15u) * 4u);
+        const uint32_t f = (uint32_t)__shfl((int)q.face, from);
+        const float t = ANY ? 0.0f : __shfl(q.t, from), u = ANY ? 0.0f : __shfl(q.u, from), v = ANY ? 0.0f : __shfl(q.v, from);
+        if (need && my_rank >= base && my_rank < base + 16u) { out.face = f; out.t = t; out.u = u; out.v = v; }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // The two object loops of trace(), each in two forms:
 //   QUAD = false  one ray per lane (64 per wave). Spheres and planes are tested in place; a ray that passes a mesh's
@@ -416,7 +451,7 @@ struct HitState { float dist; V3 n; int cur; uint32_t mat; float tmpdist; };
 // Closest-hit loop (reference src/raytracer.cpp:292-300): objects in scene order, strict <. Returns -1 when the loop
 // ran to its end, else (QUAD = false only) the index of the mesh object the ray suspended at, with `h` as it was
 // before that object.
-template <bool QUAD, bool COUNT, bool PACKET = false>
+template <bool QUAD, bool COUNT, int PACKET = 0>      // PACKET (per-lane form): 0 suspend at a mesh, 1 packets, 2 quad service
 __device__ __forceinline__ int closest_loop(const DScene& S, const Ray& ray, bool alive, uint32_t k0, HitState& h,
                                             uint32_t* qs, Work& wk) {
     int susp = -1;
@@ -452,7 +487,9 @@ __device__ __forceinline__ int closest_loop(const DScene& S, const Ray& ray, boo
                 if (go) h.tmpdist = FLT_MAX;
                 QuadHit q;
                 q.face = 0xFFFFFFFFu; q.t = 0; q.u = 0; q.v = 0;
-                if (PACKET) {
+                if (PACKET == 2) {
+                    serve_traverse<false, COUNT>(S, m.root, need, ray, FLT_MAX, q, qs, wk);
+                } else if (PACKET) {
                     if (__ballot(need)) packet_traverse<false, COUNT>(S, m.root, need, ray, FLT_MAX, q, wk);
                 } else if (need) {
                     quad_traverse<false, COUNT>(S, m.root, true, ray, FLT_MAX, q, qs, wk);
@@ -481,7 +518,7 @@ __device__ __forceinline__ int closest_loop(const DScene& S, const Ray& ray, boo
 
 // Shadow loop (reference src/raytracer.cpp:319-325): any object with hit && tmpdist < ldist; the loop breaks at the
 // first one, so later objects no longer touch tmpdist. `susp` as in closest_loop.
-template <bool QUAD, bool COUNT, bool PACKET = false>
+template <bool QUAD, bool COUNT, int PACKET = 0>
 __device__ __forceinline__ bool occluded_loop(const DScene& S, const Ray& ray, bool alive, uint32_t k0, float ldist,
                                               float& tmpdist, int& susp, uint32_t* qs, Work& wk) {
     V3 tmpnormal;
@@ -520,7 +557,9 @@ __device__ __forceinline__ bool occluded_loop(const DScene& S, const Ray& ray, b
             } else {
                 QuadHit q;
                 q.face = 0xFFFFFFFFu;
-                if (PACKET) {
+                if (PACKET == 2) {
+                    serve_traverse<true, COUNT>(S, m.root, need, ray, ldist, q, qs, wk);
+                } else if (PACKET) {
                     if (__ballot(need)) packet_traverse<true, COUNT>(S, m.root, need, ray, ldist, q, wk);
                 } else if (need) {
                     quad_traverse<true, COUNT>(S, m.root, true, ray, ldist, q, qs, wk);
@@ -946,8 +985,8 @@ __device__ __forceinline__ void locate(const Groups& G, uint32_t grp, uint32_t& 
 }
 
 // k_extend_wide: one ray per lane. Rays that never reach a mesh are finished here; the others are queued.
-template <int SRC, bool COUNT, bool PACKET>
-__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(PACKET ? RT_WPE_PK : RT_WPE_EW))) void k_extend_wide(DScene S, LevelArgs A) {
+template <int SRC, bool COUNT, int PACKET>
+__device__ __forceinline__ void extend_wide_body(const DScene& S, const LevelArgs& A, uint32_t* lds) {
     const bool level0 = SRC != 1;
     const ShardView v = shard_view(A, A.level, A.level);
     const Groups G = level0 ? make_groups_dense<false>(A.n0, A.chunk_log2) : make_groups<false>(v.start, v.cnt);
@@ -965,7 +1004,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(PACKET
         const bool valid = active && fetch_ray<SRC>(A, 0, i, ray);
         HitState h = fresh_hit();
         int susp = -1;
-        if (!(A.debug & 2u)) susp = closest_loop<false, COUNT, PACKET>(S, ray, valid, 0, h, nullptr, wk);
+        if (!(A.debug & 2u)) susp = closest_loop<false, COUNT, PACKET>(S, ray, valid, 0, h, lds, wk);
         const bool parked = susp >= 0;
         ShardCounters* sc = A.sc + shard;
         uint32_t qslot = 0;
@@ -979,7 +1018,17 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(PACKET
         extend_finish(S, A, i, active && !parked, valid && !parked, true, ray, h, lane_read(next_base_l, shard),
                       A.n0 + (shard + 1u) * A.sub_cap, sc->level + (A.level + 1), 0u);
     }
-    if (COUNT) flush_work(A.work, 0, wk);
+    if (COUNT) flush_work(A.work, PACKET == 2 ? 2 : 0, wk);
+}
+template <int SRC, bool COUNT, bool PACKET>
+__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(PACKET ? RT_WPE_PK : RT_WPE_EW))) void k_extend_wide(DScene S, LevelArgs A) {
+    extend_wide_body<SRC, COUNT, PACKET ? 1 : 0>(S, A, nullptr);
+}
+// the rays of a level >= 1, one per lane, meshes by quad service
+template <bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WPE_EQ))) void k_extend_serve(DScene S, LevelArgs A) {
+    __shared__ uint32_t lds_stack[RT_QSTACK * 16];
+    extend_wide_body<1, COUNT, 2>(S, A, lds_stack);
 }
 
 // k_extend_quad: one ray per quad. FRESH: all rays of the level from the start (levels with few rays: no per-lane
@@ -1060,7 +1109,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WPE
 // Light loop of trace() (reference src/raytracer.cpp:311-345) for one hit, starting at light li0 / object k0 of its
 // shadow loop (0/0, or where the per-lane kernel suspended). Writes node_a[i]; on suspension (QUAD = false) node_a[i]
 // holds {colour so far, tmpdist} and `parked` gets (li << 16) | k. Convergent.
-template <bool QUAD, bool COUNT, bool GPOW, bool PACKET = false>
+template <bool QUAD, bool COUNT, bool GPOW, int PACKET = 0>
 __device__ __forceinline__ void shade_ray(const DScene& S, const LevelArgs& A, uint32_t i, uint4 b, bool hit, bool writer,
                                           V3 hitNormal, V3 hitPt, float rCoef, float tmpdist, uint32_t li0, uint32_t k0,
                                           bool resumed, V3 color, uint32_t* qs, Work& wk, uint32_t& n_shadow, int& parked) {
@@ -1129,8 +1178,8 @@ __device__ __forceinline__ void flush_shadow(const LevelArgs& A, uint32_t n_shad
 
 // k_shade_wide: light loop, one hit per lane, for the hits of levels A.level..A.level_hi. Hits whose shadow rays never
 // reach a mesh are finished here; the others are queued (queue of A.level) at the point they stopped.
-template <bool COUNT, bool GPOW, bool PACKET>
-__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(PACKET ? RT_WPE_PK : RT_WPE_SW))) void k_shade_wide(DScene S, LevelArgs A) {
+template <bool COUNT, bool GPOW, int PACKET>
+__device__ __forceinline__ void shade_wide_body(const DScene& S, const LevelArgs& A, uint32_t* lds) {
     const bool level0 = A.level == 0;                 // then level_hi == 0: level 0 is not part of a range
     const ShardView v = shard_view(A, A.level, A.level_hi);
     const Groups G = level0 ? make_groups_dense<false>(A.n0, A.chunk_log2) : make_groups<false>(v.start, v.cnt);
@@ -1148,7 +1197,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(PACKET
         float4 hn = make_float4(0, 0, 0, 0), hp = make_float4(0, 0, 0, 0);
         if (hit) { hn = A.hit_n[i]; hp = A.hit_p[i]; }
         int parked;
-        shade_ray<false, COUNT, GPOW, PACKET>(S, A, i, b, hit, true, f4xyz(hn), f4xyz(hp), hp.w, hn.w, 0, 0, false, mk(0, 0, 0), nullptr, wk,
+        shade_ray<false, COUNT, GPOW, PACKET>(S, A, i, b, hit, true, f4xyz(hn), f4xyz(hp), hp.w, hn.w, 0, 0, false, mk(0, 0, 0), lds, wk,
                                 n_shadow, parked);
         if (level0) {       // mark; hit_n.w (tmpdist at the start of the light loop) is not needed again: keep the resume point there
             if (parked >= 0) { A.node_b[i].w = b.w | NODE_SPARKED; A.hit_n[i].w = __uint_as_float((uint32_t)parked); }
@@ -1158,7 +1207,17 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(PACKET
         }
     }
     flush_shadow(A, n_shadow);
-    if (COUNT) flush_work(A.work, 1, wk);
+    if (COUNT) flush_work(A.work, PACKET == 2 ? 3 : 1, wk);
+}
+template <bool COUNT, bool GPOW, bool PACKET>
+__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(PACKET ? RT_WPE_PK : RT_WPE_SW))) void k_shade_wide(DScene S, LevelArgs A) {
+    shade_wide_body<COUNT, GPOW, PACKET ? 1 : 0>(S, A, nullptr);
+}
+// the hits of levels >= 1, one per lane, shadow rays through meshes by quad service
+template <bool COUNT, bool GPOW>
+__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void k_shade_serve(DScene S, LevelArgs A) {
+    __shared__ uint32_t lds_stack[RT_QSTACK * 16];
+    shade_wide_body<COUNT, GPOW, 2>(S, A, lds_stack);
 }
 
 // k_shade_quad: light loop, one hit per quad.
@@ -1448,6 +1507,9 @@ static void launch_extend_src(int form, bool count, const DScene& S, const Level
             if (count) hipLaunchKernelGGL((k_extend_wide<SRC, true, false>), g, b, 0, st, S, A);
             else hipLaunchKernelGGL((k_extend_wide<SRC, false, false>), g, b, 0, st, S, A);
         }
+    } else if (form == RT_FORM_WIDE_SERVE) {
+        if (count) hipLaunchKernelGGL((k_extend_serve<true>), g, b, 0, st, S, A);
+        else hipLaunchKernelGGL((k_extend_serve<false>), g, b, 0, st, S, A);
     } else if (form == RT_FORM_QUAD_FRESH) {
         if (count) hipLaunchKernelGGL((k_extend_quad<SRC, true, true>), g, b, 0, st, S, A);
         else hipLaunchKernelGGL((k_extend_quad<SRC, true, false>), g, b, 0, st, S, A);
@@ -1468,6 +1530,7 @@ static void launch_shade_t(int form, const DScene& S, const LevelArgs& A, dim3 g
         if (S.packet && (A.level == 0 || S.packet >= 2) && !A.user_rays) hipLaunchKernelGGL((k_shade_wide<COUNT, GPOW, true>), g, b, 0, st, S, A);
         else hipLaunchKernelGGL((k_shade_wide<COUNT, GPOW, false>), g, b, 0, st, S, A);
     }
+    else if (form == RT_FORM_WIDE_SERVE) hipLaunchKernelGGL((k_shade_serve<COUNT, GPOW>), g, b, 0, st, S, A);
     else if (form == RT_FORM_QUAD_FRESH) hipLaunchKernelGGL((k_shade_quad<0, COUNT, GPOW>), g, b, 0, st, S, A);
     else if (form == RT_FORM_QUAD_RESUME) hipLaunchKernelGGL((k_shade_quad<1, COUNT, GPOW>), g, b, 0, st, S, A);
     else hipLaunchKernelGGL((k_shade_quad<2, COUNT, GPOW>), g, b, 0, st, S, A);

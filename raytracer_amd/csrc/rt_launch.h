@@ -129,7 +129,9 @@ struct UntileArgs {
 
 // Kernel forms: one ray per lane (suspends at meshes), one ray per quad from the start, one per quad resuming the queue.
 // RT_FORM_QUAD_PARKED (shade only): one hit per quad from the start, for the rays of the level's extend queue.
-enum { RT_FORM_WIDE = 0, RT_FORM_QUAD_FRESH = 1, RT_FORM_QUAD_RESUME = 2, RT_FORM_QUAD_PARKED = 3 };
+// RT_FORM_WIDE_SERVE (levels >= 1): one ray / hit per lane like RT_FORM_WIDE, but nothing is suspended: the lanes whose ray
+// reaches a mesh are served 16 at a time by the wave's own quads (serve_traverse).
+enum { RT_FORM_WIDE = 0, RT_FORM_QUAD_FRESH = 1, RT_FORM_QUAD_RESUME = 2, RT_FORM_QUAD_PARKED = 3, RT_FORM_WIDE_SERVE = 4 };
 void launch_extend(int src, int form, bool count, const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st);
 void launch_shade(int form, bool count, const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st);
 void launch_set_frame_params(const FrameParamsBatch& p, uint32_t n_frames, FrameParams* dst, void* clear, size_t clear_bytes, hipStream_t st);   // clear: 16-byte multiple
