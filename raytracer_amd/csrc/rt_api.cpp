@@ -620,13 +620,13 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
         // field 5.40 -> 5.22); a smaller pass keeps one ray per quad, whose waves are a quarter as long (one 1080p frame at
         // a time: 0.73 ms against 0.91 with quad service). RT_SERVE=0/1 overrides.
         const int serve_env = std::getenv("RT_SERVE") ? std::atoi(std::getenv("RT_SERVE")) : -1;
-        const bool serve = s->d.packet == 1 && (serve_env >= 0 ? serve_env != 0 : A.n0 >= (4u << 20));
+        const bool serve = s->d.packet >= 1 && (serve_env >= 0 ? serve_env != 0 : (s->d.packet == 1 && A.n0 >= (4u << 20)));
         const bool split_small = std::getenv("RT_SPLIT_SMALL") ? std::atoi(std::getenv("RT_SPLIT_SMALL")) != 0 : true;
         auto shade_small = [&](int lo, int hi, int after) -> int {
             // (not where the per-lane kernels traverse meshes as packets at every level: the rays of a small bounce level
             // have nothing in common - 10 M-triangle field at 8K 64 spp 717 -> 970 ms)
-            if (!split_small || s->d.packet >= 2) return shade(RT_FORM_QUAD_FRESH, lo, hi, after);
             if (serve && level_hint(s, slot, lo) < 0xFFFFFFFFull) return shade(RT_FORM_WIDE_SERVE, lo, hi, after, true);
+            if (!split_small || s->d.packet >= 2) return shade(RT_FORM_QUAD_FRESH, lo, hi, after);
             const int rc2 = shade(RT_FORM_WIDE, lo, hi, after, true);
             if (rc2 != RT_OK) return rc2;
             return shade(RT_FORM_QUAD_RESUME, lo, hi, after, true);
