@@ -26,6 +26,12 @@ if serial:
         if cnt[j]:
             print(f"HIP events: {names[j]}: {cnt[j]} launches, average {ms[j] / cnt[j] * 1e3:.1f} us")
 else:
-    for _ in range(n):
-        dev.render_device(cam, p, frame.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    B = int(os.environ.get("ONE_FRAME_BATCH", "1"))      # frames per call (the counters of the last CALL are what the PMC scripts sum)
+    if B > 1:
+        frames = torch.zeros((B, cam.imHeight, cam.imWidth, 3), dtype=torch.uint8, device="cuda")
+        for _ in range(n):
+            dev.render_batch_device([cam] * B, p, frames.data_ptr(), cam.imHeight * cam.imWidth * 3, stream=torch.cuda.current_stream().cuda_stream)
+    else:
+        for _ in range(n):
+            dev.render_device(cam, p, frame.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
 torch.cuda.synchronize()
