@@ -370,21 +370,28 @@ __device__ __forceinline__ void packet_traverse(const DScene& S, uint32_t root, 
             const uint32_t cnt = ((cur >> 27) & 15u) + 1u;
             const RT_CONSTANT u32x4* lp = (const RT_CONSTANT u32x4*)(const void*)(S.leaves) + 12u * (size_t)(cur & RT_LEAF_START_MASK);
             if (COUNT) { wk.tris += live ? cnt : 0u; wk.wave_tris += wave_once(); }
-            // the whole block (192 B, always allocated in full) in one go, as for a node
-            u32x4 lf[12];
+            // two triangles per request (6 x 16 B, one wait): four requests one after the other are four latencies, the whole
+            // block at once (48 SGPRs) makes the kernel spill scalars around the loop - and every spilled SGPR is a VALU
+            // instruction (v_writelane / v_readlane), which is what this path is short of
 #pragma unroll
-            for (int c = 0; c < 12; ++c) lf[c] = lp[c];
+            for (uint32_t t0 = 0; t0 < RT_MAX_LEAF_TRIS; t0 += 2) {
+                if (t0 < cnt) {                                                                  // wave-uniform
+                    u32x4 lf[6];
 #pragma unroll
-            for (uint32_t t = 0; t < RT_MAX_LEAF_TRIS; ++t) {
-                if (t < cnt) {                                                                   // wave-uniform
-                    const float4 q0 = as_f4(lf[t]), q1 = as_f4(lf[4 + t]), q2 = as_f4(lf[8 + t]);
-                    float tt, u, v;
-                    if (live && tri_isect(f4xyz(q0), f4xyz(q1), f4xyz(q2), ray, tt, u, v)) {
-                        const uint32_t f = __float_as_uint(q0.w);
-                        if (ANY) {
-                            if (tt < tmax) { face = 0; live = false; }
-                        } else if (tt < best || (tt == best && f < face)) {
-                            best = tt; bu = u; bv = v; face = f;
+                    for (int c = 0; c < 3; ++c) { lf[2 * c] = lp[4 * c + t0]; lf[2 * c + 1] = lp[4 * c + t0 + 1]; }
+#pragma unroll
+                    for (uint32_t dt = 0; dt < 2; ++dt) {
+                        if (t0 + dt < cnt) {                                                     // wave-uniform
+                            const float4 q0 = as_f4(lf[dt]), q1 = as_f4(lf[2 + dt]), q2 = as_f4(lf[4 + dt]);
+                            float tt, u, v;
+                            if (live && tri_isect(f4xyz(q0), f4xyz(q1), f4xyz(q2), ray, tt, u, v)) {
+                                const uint32_t f = __float_as_uint(q0.w);
+                                if (ANY) {
+                                    if (tt < tmax) { face = 0; live = false; }
+                                } else if (tt < best || (tt == best && f < face)) {
+                                    best = tt; bu = u; bv = v; face = f;
+                                }
+                            }
                         }
                     }
                 }
