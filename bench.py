@@ -134,7 +134,14 @@ def main():
     multi = world > 1 or args.rehearse_exchange        # the N-rank code path
     if multi:
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            # No device_id: the RCCL communicator is then created by the first collective (the first warmup call's gather),
+            # i.e. AFTER the scenes have created their streams. Created before them (device_id = eager), RCCL's own streams
+            # shift the scenes' streams onto other hardware queues and every frame takes 1.5x as long (one rank, exchange
+            # included: 0.46 ms against 0.31; tools/exp_rehearse2.sh). BENCH_EAGER_PG=1 brings the eager order back.
+            if os.environ.get("BENCH_EAGER_PG"):
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            else:
+                dist.init_process_group("nccl")
         else:
             dist.init_process_group(args.backend)
 
@@ -204,7 +211,9 @@ def main():
                 sl.dev.render_batch_device(cams[:b], params, sl.frames.data_ptr(), frame_bytes, stream=h)
                 return
             sl.dev.render_tiles_batch_device(cams[:b], params, (tw, th), rank, world, sl.mine.data_ptr(), sl.part_bytes, stream=h)
-            if args.backend == "nccl":
+            if "gather" in os.environ.get("BENCH_SKIP", ""):     # diagnostics: time the path without its exchange / untile
+                pass
+            elif args.backend == "nccl":
                 dist.gather(sl.mine, sl.gathered, dst=0)        # ONE exchange for the b frames
             else:       # gloo rehearsal: gloo gathers host tensors only
                 sl.stream.synchronize()
@@ -213,7 +222,7 @@ def main():
                 dist.gather(host, hg, dst=0)
                 if rank == 0:
                     sl.allt.copy_(torch.cat(hg))
-            if rank == 0:       # part q's tiles of frame k start at tile slot q * B * n_slot + k * n_slot; one launch
+            if rank == 0 and "untile" not in os.environ.get("BENCH_SKIP", ""):       # part q's tiles of frame k start at tile slot q * B * n_slot + k * n_slot; one launch
                 cabi.check(lib, lib.rt_untile_batch_device(local, W, H, tw, th, world, B * sl.n_slot, b, sl.part_bytes,
                                                            frame_bytes, C.c_void_p(sl.allt.data_ptr()),
                                                            C.c_void_p(sl.frames.data_ptr()), C.c_void_p(h)))
@@ -228,8 +237,8 @@ def main():
             call += 1
 
     def sync():
-        if multi:
-            dist.barrier()
+        if multi and "barrier" not in os.environ.get("BENCH_SKIP", ""):
+            dist.barrier(device_ids=[local]) if args.backend == "nccl" else dist.barrier()
         torch.cuda.synchronize()
 
     def overflowed():
@@ -240,7 +249,7 @@ def main():
                 sl.dev.status()
             except cabi.RtError:
                 bad = 1
-        if multi:
+        if multi and "barrier" not in os.environ.get("BENCH_SKIP", ""):
             f = torch.tensor([bad], dtype=torch.int32, device="cuda" if args.backend == "nccl" else "cpu")
             dist.all_reduce(f, op=dist.ReduceOp.MAX)
             bad = int(f.item())
@@ -260,7 +269,7 @@ def main():
     elapsed = time.perf_counter() - t
     if overflowed():
         raise SystemExit("bench.py: a timed frame ran out of ray pool; the measurement is void")
-    if multi:
+    if multi and "barrier" not in os.environ.get("BENCH_SKIP", ""):
         e = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(e, op=dist.ReduceOp.MAX)
         elapsed = float(e.item())
@@ -410,7 +419,7 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(fs, cam, params, dev, np)
         print(json.dumps(out), flush=True)
     if multi:
-        dist.barrier()
+        dist.barrier(device_ids=[local]) if args.backend == "nccl" else dist.barrier()
         dist.destroy_process_group()
 
 
