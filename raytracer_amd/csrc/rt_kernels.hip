@@ -706,6 +706,12 @@ __device__ __forceinline__ bool map_pixel(const PixelMap& pm, uint64_t q, uint32
 #ifndef RT_WPE_EW
 #define RT_WPE_EW 7
 #endif
+#ifndef RT_WPE_ES
+#define RT_WPE_ES 5      // k_extend_serve (95 VGPRs, nothing spilled)
+#endif
+#ifndef RT_WPE_SS
+#define RT_WPE_SS 4      // k_shade_serve (5: 96 VGPRs with 11 spilled)
+#endif
 #ifndef RT_WPE_PK
 #define RT_WPE_PK 5      // the per-lane kernels when they carry the packet traversal
 #endif
@@ -1033,7 +1039,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(PACKET
 }
 // the rays of a level >= 1, one per lane, meshes by quad service
 template <bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WPE_EQ))) void k_extend_serve(DScene S, LevelArgs A) {
+__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WPE_ES))) void k_extend_serve(DScene S, LevelArgs A) {
     __shared__ uint32_t lds_stack[RT_QSTACK * 16];
     extend_wide_body<1, COUNT, 2>(S, A, lds_stack);
 }
@@ -1222,7 +1228,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(PACKET
 }
 // the hits of levels >= 1, one per lane, shadow rays through meshes by quad service
 template <bool COUNT, bool GPOW>
-__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void k_shade_serve(DScene S, LevelArgs A) {
+__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WPE_SS))) void k_shade_serve(DScene S, LevelArgs A) {
     __shared__ uint32_t lds_stack[RT_QSTACK * 16];
     shade_wide_body<COUNT, GPOW, 2>(S, A, lds_stack);
 }
