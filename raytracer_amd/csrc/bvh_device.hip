@@ -288,7 +288,7 @@ __global__ void k_emit4(Ctx c) {
 
 struct Buf {
     void* p = nullptr;
-    ~Buf() { if (p) hipFree(p); }
+    ~Buf() { if (p) (void)hipFree(p); }
     template <typename T> T* get(size_t n) { if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) p = nullptr; return static_cast<T*>(p); }
 };
 
@@ -411,7 +411,7 @@ int bvh_build_device(const rt_flat_scene* sc, DeviceBvh* out) {
     // exact-size copies for the scene to keep
     TRY(hipMalloc(reinterpret_cast<void**>(&out->nodes), sizeof(Bvh4Node) * std::max<uint32_t>(1, node_base)));
     if (hipMalloc(reinterpret_cast<void**>(&out->leaves), sizeof(LeafBlock) * std::max<uint32_t>(1, leaf_base)) != hipSuccess) {
-        hipFree(out->nodes); out->nodes = nullptr;
+        (void)hipFree(out->nodes); out->nodes = nullptr;
         rt_set_error("device BVH build: out of memory");
         return -1;
     }
