@@ -713,7 +713,7 @@ __device__ __forceinline__ bool map_pixel(const PixelMap& pm, uint64_t q, uint32
 #define RT_WPE_SS 4      // k_shade_serve (5: 96 VGPRs with 11 spilled)
 #endif
 #ifndef RT_WPE_PK
-#define RT_WPE_PK 5      // the per-lane kernels when they carry the packet traversal
+#define RT_WPE_PK 7      // the per-lane kernels when they carry the packet traversal (5/6: bunny_1080p 0.292 ms, 7: 0.281, 8: 0.301; 4K glass scene 43.8 / 42.4 / 43.5)
 #endif
 #define RT_RUN_LOG2 3u    // see group_of: runs of 8 groups (measured: 1, 2, 4 and 16 within 3 %; 64+ and one strip per CU 5-20 % slower). Experiments: RT_DEBUG_SKIP = run_log2 << 8
 #define NODE_HIT 4u      // has a hit record: k_shade computes its colour
