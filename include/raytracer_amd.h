@@ -239,6 +239,30 @@ int rt_occluded(rt_scene* scene, const float* rays, const float* max_dist, uint3
 int rt_trace(rt_scene* scene, const rt_params* params, const float* rays, uint32_t n_rays,
              float* rgb_out, rt_stats* stats);
 
+/* The same three with the mesh traversal chosen by the caller. The renderer takes a ray through a Model
+ * (reference src/primitives.cpp:364-384: every face, lowest index wins ties) in one of three ways, picked per level
+ * by ray coherence and level size; all three must give the reference's result bit for bit, so the parity tests run
+ * the same rays through each:
+ *   RT_TRAVERSE_QUAD    one ray per quad of lanes (what rt_intersect / rt_occluded / rt_trace use)
+ *   RT_TRAVERSE_PACKET  one ray per lane, the wave's 64 rays walk the tree together; rays are taken 64 at a time in
+ *                       the order given (primary rays and their shadow rays in rt_render)
+ *   RT_TRAVERSE_SERVE   one ray per lane, the lanes that reach a mesh are served by the wave's own quads
+ *                       (bounce levels of large passes in rt_render)
+ * rt_trace_form applies the form to every recursion level and to the shadow rays. */
+enum { RT_TRAVERSE_QUAD = 0, RT_TRAVERSE_PACKET = 1, RT_TRAVERSE_SERVE = 2 };
+int rt_intersect_form(rt_scene* scene, int form, int object, const float* rays, uint32_t n_rays,
+                      int32_t* hit_obj_out, float* dist_out, float* normal_out);
+int rt_occluded_form(rt_scene* scene, int form, const float* rays, const float* max_dist, uint32_t n_rays,
+                     uint8_t* occluded_out);
+int rt_trace_form(rt_scene* scene, int form, const rt_params* params, const float* rays, uint32_t n_rays,
+                  float* rgb_out, rt_stats* stats);
+
+/* Level-0 samples per pass: a frame with more samples is rendered in passes of whole pixels that reuse one
+ * workspace (default 2^23; `samples` a power of two in [2^12, 2^26], 0 = the default). Waits for the scene's
+ * frames in flight. Results never depend on it. No counterpart in the reference (its recursion needs no workspace);
+ * for callers that bound the scene's HBM use (6 x 112 B per sample of a pass) and for the multi-pass parity tests. */
+int rt_scene_set_pass_samples(rt_scene* scene, uint32_t samples);
+
 /* BVH introspection for tests and the roofline's algorithmic bytes/flops. */
 typedef struct rt_bvh_info {
     uint32_t n_nodes;

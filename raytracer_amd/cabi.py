@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(HERE, "csrc", "librt_amd.so")
 
 RT_SCENE_BVH_DEVICE = 1
 RT_OBJ_SPHERE, RT_OBJ_PLANE, RT_OBJ_MODEL = 0, 1, 2
+RT_TRAVERSE_QUAD, RT_TRAVERSE_PACKET, RT_TRAVERSE_SERVE = 0, 1, 2
 
 
 class rt_material(C.Structure):
@@ -108,6 +109,7 @@ EXPORTS = [
     "rt_scene_create", "rt_scene_create_ex", "rt_scene_destroy", "rt_render", "rt_render_device", "rt_render_tiles_device",
     "rt_render_batch_device", "rt_render_tiles_batch_device",
     "rt_tiles_owned", "rt_untile_device", "rt_untile_batch_device", "rt_cast_rays", "rt_intersect", "rt_occluded", "rt_trace",
+    "rt_intersect_form", "rt_occluded_form", "rt_trace_form", "rt_scene_set_pass_samples",
     "rt_scene_bvh_info", "rt_bvh_check", "rt_scene_bvh_check", "rt_scene_status", "rt_scene_stream", "rt_set_count_work", "rt_get_work", "rt_last_error", "rt_version",
 ]
 
@@ -156,6 +158,10 @@ def load(path=None):
     lib.rt_intersect.argtypes = [vp, C.c_int, FP, u32, C.POINTER(C.c_int32), FP, FP]
     lib.rt_occluded.argtypes = [vp, FP, FP, u32, C.POINTER(C.c_uint8)]
     lib.rt_trace.argtypes = [vp, C.POINTER(rt_params), FP, u32, FP, C.POINTER(rt_stats)]
+    lib.rt_intersect_form.argtypes = [vp, C.c_int, C.c_int, FP, u32, C.POINTER(C.c_int32), FP, FP]
+    lib.rt_occluded_form.argtypes = [vp, C.c_int, FP, FP, u32, C.POINTER(C.c_uint8)]
+    lib.rt_trace_form.argtypes = [vp, C.c_int, C.POINTER(rt_params), FP, u32, FP, C.POINTER(rt_stats)]
+    lib.rt_scene_set_pass_samples.argtypes = [vp, u32]
     lib.rt_scene_bvh_info.argtypes = [vp, C.POINTER(rt_bvh_info)]
     lib.rt_bvh_check.argtypes = [C.POINTER(rt_flat_scene), C.POINTER(rt_bvh_check_result)]
     lib.rt_scene_bvh_check.argtypes = [vp, C.POINTER(rt_flat_scene), C.POINTER(rt_bvh_check_result)]

@@ -54,11 +54,15 @@ struct PassCounters {                 // one per pass, zeroed by one memset per 
 };
 
 #define RT_MAX_PASSES 1024
-static uint32_t pass_samples() {      // level-0 samples per pass (RT_PASS_LOG2 in the environment: experiments)
-    static const uint32_t n = [] { const char* e = std::getenv("RT_PASS_LOG2"); const int k = e ? std::atoi(e) : 23; return 1u << std::max(12, std::min(26, k)); }();
-    return n;
+#define RT_PASS_LOG2_MIN 12
+#define RT_PASS_LOG2_MAX 26
+// Level-0 samples per pass of a new scene: 8 M (RT_PASS_LOG2 in the environment for experiments). A property of the
+// scene (rt_scene::pass_samples, rt_scene_set_pass_samples), read when the scene is created.
+static uint32_t default_pass_samples() {
+    const char* e = std::getenv("RT_PASS_LOG2");
+    const int k = e ? std::atoi(e) : 23;
+    return 1u << std::max(RT_PASS_LOG2_MIN, std::min(RT_PASS_LOG2_MAX, k));
 }
-#define RT_PASS_SAMPLES pass_samples()
 #define RT_POOL_FACTOR 6u             // node pool = 6x the pass size when materials bounce (level 0 + 5x for deeper levels)
 #define RT_MAX_TIMED 2048
 #define RT_MAX_GRAPHS 8
@@ -114,7 +118,10 @@ struct rt_scene {
     hipStream_t last_stream = nullptr;   // stream of the most recent asynchronous frame
     uint32_t last_spp = 1;
     uint32_t ws_min_n0 = 0;              // the workspace is sized for at least this many samples per pass (grown after overflows)
+    uint32_t pass_samples = 1u << 23;    // level-0 samples per pass (frames with more are cut into passes of whole pixels)
 };
+#define RT_PASS_SAMPLES (s->pass_samples)
+#define RT_POOL_MAX_N0 std::max<uint32_t>(s->pass_samples, 1u << 23)   // a pool that overflowed on 64 pixels grows up to that of a default pass
 
 static int free_scene(rt_scene* s) {
     if (!s) return RT_OK;
@@ -260,7 +267,8 @@ extern "C" int rt_scene_create_ex(const rt_flat_scene* sc, int device, uint32_t 
     s->packet_auto = true;
     s->d.packet = sc->n_models > 0 ? 1u : 0u;
     if (const char* e = std::getenv("RT_PACKET")) { s->d.packet = sc->n_models > 0 ? uint32_t(std::atoi(e)) : 0u; s->packet_auto = false; }
-    s->d.pad = 0;
+    s->d.user_packet = 0;
+    s->pass_samples = default_pass_samples();
     if ((rc = upload(s, objs.data(), objs.size(), &s->d.objects)) != RT_OK) return fail(rc);
     if ((rc = upload(s, models.data(), models.size(), &s->d.models)) != RT_OK) return fail(rc);
     if ((rc = upload(s, sc->materials, size_t(sc->n_materials), &s->d.materials)) != RT_OK) return fail(rc);
@@ -322,6 +330,21 @@ extern "C" int rt_scene_status(rt_scene* s) {
 }
 
 extern "C" void* rt_scene_stream(const rt_scene* s) { return s ? static_cast<void*>(s->stream) : nullptr; }
+
+extern "C" int rt_scene_set_pass_samples(rt_scene* s, uint32_t samples) {
+    if (!s) { rt_set_error("null scene"); return RT_ERR_INVALID; }
+    if (samples == 0) { s->pass_samples = default_pass_samples(); return RT_OK; }
+    if (samples < (1u << RT_PASS_LOG2_MIN) || samples > (1u << RT_PASS_LOG2_MAX) || (samples & (samples - 1u))) {
+        rt_set_error("pass size %u is not a power of two in [2^%d, 2^%d]", samples, RT_PASS_LOG2_MIN, RT_PASS_LOG2_MAX);
+        return RT_ERR_LIMIT;
+    }
+    HIP_TRY(hipSetDevice(s->device));
+    if (s->last_stream) HIP_TRY(hipStreamSynchronize(s->last_stream));      // frames in flight keep their passes
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    s->pass_samples = samples;
+    s->shrink_log2 = 0;
+    return RT_OK;
+}
 
 extern "C" int rt_scene_bvh_info(const rt_scene* s, rt_bvh_info* out) {
     if (!s || !out) { rt_set_error("null argument"); return RT_ERR_INVALID; }
@@ -575,7 +598,11 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
         const uint32_t grid0q = std::min<uint32_t>((A.n0 + 15) / 16, 4u * RT_LEVEL_GRID);
         int rc;
         bool used_shade[3] = {false, false, false};
+        // a shade stream waits for an event once per RECORDING of it: slots are re-recorded within a pass (ev_sync[2*lv]
+        // before shade_small and again after that level's per-lane extend), so the elision compares (slot, generation)
         int last_wait[3] = {-1, -1, -1};
+        int ev_gen[2 * RT_MAX_LEVELS + 5] = {};
+        auto record = [&](int slot) -> hipError_t { ++ev_gen[slot]; return hipEventRecord(s->ev_sync[slot], sa); };
         // (a "lean" schedule for small passes - one shade stream, one shade launch for all small levels, deep levels folded
         // by one workgroup, 30 API calls instead of 50 - was measured SLOWER: 0.27 vs 0.24 ms for an eighth of the frame)
         // diagnostics: RT_WAVE_LOG=<level>:<file> dumps per-workgroup timing of that level's quad extend kernel (COUNT builds)
@@ -595,8 +622,9 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
             const int which = ((form == RT_FORM_QUAD_FRESH || small_run) ? 2 : (lo & 1)) % s->n_shade_streams;
             hipStream_t sb = overlap ? s->shade_stream[which] : sa;
             if (overlap) {
-                if (last_wait[which] != after) HIP_TRY(hipStreamWaitEvent(sb, s->ev_sync[after], 0));
-                last_wait[which] = after;
+                const int stamp = after * 65536 + ev_gen[after];
+                if (last_wait[which] != stamp) HIP_TRY(hipStreamWaitEvent(sb, s->ev_sync[after], 0));
+                last_wait[which] = stamp;
                 used_shade[which] = true;
             }
             // level 0 lies in sample order, the deeper levels in the sub-pools: a range that starts at level 0 is two launches
@@ -643,18 +671,18 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
             const bool large = !meshes || lv == 0 || expect_large(s, slot, lv, lv);
             if (large) {
                 if (small_lo >= 0) {     // shade the small levels before this one
-                    if (overlap) HIP_TRY(hipEventRecord(s->ev_sync[2 * lv], sa));
+                    if (overlap) HIP_TRY(record(2 * lv));
                     if ((rc = shade_small(small_lo, lv - 1, 2 * lv)) != RT_OK) return rc;
                     small_lo = -1;
                 }
                 if ((rc = timed_launch(J, sa, RT_K_EXTEND_WIDE, [&] { launch_extend(src, RT_FORM_WIDE, s->count_work, s->d, B, lv == 0 ? grid0 : RT_LEVEL_GRID, sa); })) != RT_OK) return rc;
-                if (overlap) HIP_TRY(hipEventRecord(s->ev_sync[2 * lv], sa));
+                if (overlap) HIP_TRY(record(2 * lv));
                 // level 0 of a packet scene: the per-lane kernels traverse the meshes themselves, nothing is suspended
                 const bool quads = meshes && !((lv == 0 && s->d.packet) || s->d.packet >= 2);
                 if (quads) {
                     B.wave_log = (lv == log_level) ? wave_log : nullptr;
                     if ((rc = timed_launch(J, sa, RT_K_EXTEND_QUAD, [&] { launch_extend(src, RT_FORM_QUAD_RESUME, s->count_work, s->d, B, lv == 0 ? grid0q : 4u * RT_LEVEL_GRID, sa); })) != RT_OK) return rc;
-                    if (overlap) HIP_TRY(hipEventRecord(s->ev_sync[2 * lv + 1], sa));
+                    if (overlap) HIP_TRY(record(2 * lv + 1));
                 }
                 const int ev_w = 2 * lv;
                 if ((rc = shade(RT_FORM_WIDE, lv, lv, ev_w)) != RT_OK) return rc;
@@ -674,7 +702,7 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
                 if ((rc = timed_launch(J, sa, RT_K_EXTEND_QUAD, [&] { launch_extend(src, RT_FORM_QUAD_FRESH, s->count_work, s->d, B, small_grid(s, slot, lv, lv), sa); })) != RT_OK) return rc;
                 if (small_lo < 0) small_lo = lv;
                 if (lv - small_lo + 1 >= 3 && lv < levels) {     // shade a run of three small levels while the deeper ones are traced
-                    if (overlap) HIP_TRY(hipEventRecord(s->ev_sync[2 * lv + 1], sa));
+                    if (overlap) HIP_TRY(record(2 * lv + 1));
                     if ((rc = shade_small(small_lo, lv, 2 * lv + 1)) != RT_OK) return rc;
                     small_lo = -1;
                 }
@@ -689,7 +717,7 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
         }
         if (small_lo >= 0) {
             const int ev = 2 * RT_MAX_LEVELS;
-            if (overlap) HIP_TRY(hipEventRecord(s->ev_sync[ev], sa));
+            if (overlap) HIP_TRY(record(ev));
             if ((rc = shade_small(small_lo, levels, ev)) != RT_OK) return rc;
         }
         for (int k = 0; k < 3; ++k)
@@ -718,7 +746,7 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
 // then by a larger pool.
 static void learn_from_overflow(rt_scene* s, uint32_t full_px) {
     if ((full_px >> s->shrink_log2) > 64u && s->shrink_log2 < 16) s->shrink_log2 = std::min(16u, s->shrink_log2 + 2u);
-    else s->ws_min_n0 = uint32_t(std::min<uint64_t>(RT_PASS_SAMPLES, std::max<uint64_t>(uint64_t(s->ws_n0) * 8u, 65536u)));
+    else s->ws_min_n0 = uint32_t(std::min<uint64_t>(RT_POOL_MAX_N0, std::max<uint64_t>(uint64_t(s->ws_n0) * 8u, 65536u)));
 }
 
 // Renders n_frames frames that differ only in their cameras (cam[0..n_frames)) as ONE sample range: frame b's pixels
@@ -868,9 +896,9 @@ static int render_frame(rt_scene* s, const rt_camera* cam, uint32_t n_frames, co
             if (part >= r.npx) {
                 // a 64-pixel pass cannot be cut: the pool itself has to grow (as if for a larger frame), up to the size a
                 // full pass gets. Everything enqueued so far must be done before the old arrays go.
-                if (s->ws_n0 >= RT_PASS_SAMPLES) { rt_set_error("bounce queue overflow on a 64-pixel pass with the largest pool"); return RT_ERR_OVERFLOW; }
+                if (s->ws_n0 >= RT_POOL_MAX_N0) { rt_set_error("bounce queue overflow on a 64-pixel pass with the largest pool"); return RT_ERR_OVERFLOW; }
                 HIP_TRY(hipStreamSynchronize(st));
-                s->ws_min_n0 = uint32_t(std::min<uint64_t>(RT_PASS_SAMPLES, std::max<uint64_t>(uint64_t(s->ws_n0) * 8u, 65536u)));
+                s->ws_min_n0 = uint32_t(std::min<uint64_t>(RT_POOL_MAX_N0, std::max<uint64_t>(uint64_t(s->ws_n0) * 8u, 65536u)));
                 if ((rc = ensure_workspace(s, s->ws_min_n0)) != RT_OK) return rc;
                 LevelArgs& Bn = J.base;
                 Bn.sub_cap = s->sub_cap;
@@ -1095,8 +1123,18 @@ extern "C" int rt_cast_rays(int device, const rt_camera* cam, const rt_params* p
     return RT_OK;
 }
 
+static int check_form(int form) {
+    if (form < RT_TRAVERSE_QUAD || form > RT_TRAVERSE_SERVE) { rt_set_error("traversal form %d outside [0,2]", form); return RT_ERR_INVALID; }
+    return RT_OK;
+}
+
 extern "C" int rt_intersect(rt_scene* s, int object, const float* rays, uint32_t n, int32_t* hit, float* dist, float* nrm) {
+    return rt_intersect_form(s, RT_TRAVERSE_QUAD, object, rays, n, hit, dist, nrm);
+}
+
+extern "C" int rt_intersect_form(rt_scene* s, int form, int object, const float* rays, uint32_t n, int32_t* hit, float* dist, float* nrm) {
     if (!s || !rays || !hit || !dist || !nrm) { rt_set_error("null argument"); return RT_ERR_INVALID; }
+    if (check_form(form) != RT_OK) return RT_ERR_INVALID;
     if (object >= int(s->d.n_objects)) { rt_set_error("object %d out of range", object); return RT_ERR_INVALID; }
     if (n == 0) return RT_OK;
     HIP_TRY(hipSetDevice(s->device));
@@ -1105,7 +1143,7 @@ extern "C" int rt_intersect(rt_scene* s, int object, const float* rays, uint32_t
         rt_set_error("hipMalloc failed"); return RT_ERR_DEVICE;
     }
     HIP_TRY(hipMemcpy(dr.p, rays, sizeof(float) * 6 * n, hipMemcpyHostToDevice));
-    launch_intersect(s->d, object, dr.as<float>(), n, dh.as<int32_t>(), dd.as<float>(), dn.as<float>(), nullptr);
+    launch_intersect(s->d, form, object, dr.as<float>(), n, dh.as<int32_t>(), dd.as<float>(), dn.as<float>(), nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(hit, dh.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(dist, dd.p, sizeof(float) * n, hipMemcpyDeviceToHost));
@@ -1114,23 +1152,33 @@ extern "C" int rt_intersect(rt_scene* s, int object, const float* rays, uint32_t
 }
 
 extern "C" int rt_occluded(rt_scene* s, const float* rays, const float* max_dist, uint32_t n, uint8_t* occ) {
+    return rt_occluded_form(s, RT_TRAVERSE_QUAD, rays, max_dist, n, occ);
+}
+
+extern "C" int rt_occluded_form(rt_scene* s, int form, const float* rays, const float* max_dist, uint32_t n, uint8_t* occ) {
     if (!s || !rays || !max_dist || !occ) { rt_set_error("null argument"); return RT_ERR_INVALID; }
+    if (check_form(form) != RT_OK) return RT_ERR_INVALID;
     if (n == 0) return RT_OK;
     HIP_TRY(hipSetDevice(s->device));
     DevBuf dr, dm, dout;
     if (dr.alloc(sizeof(float) * 6 * n) || dm.alloc(sizeof(float) * n) || dout.alloc(n)) { rt_set_error("hipMalloc failed"); return RT_ERR_DEVICE; }
     HIP_TRY(hipMemcpy(dr.p, rays, sizeof(float) * 6 * n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(dm.p, max_dist, sizeof(float) * n, hipMemcpyHostToDevice));
-    launch_occluded(s->d, dr.as<float>(), dm.as<float>(), n, dout.as<uint8_t>(), nullptr);
+    launch_occluded(s->d, form, dr.as<float>(), dm.as<float>(), n, dout.as<uint8_t>(), nullptr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(occ, dout.p, n, hipMemcpyDeviceToHost));
     return RT_OK;
 }
 
 // One chunk of rt_trace: rays [first, first+n) at level 0. Sets *overflow instead of failing.
-static int trace_chunk(rt_scene* s, const rt_params* prm, const float* d_rays, uint32_t n, float* d_rgb, rt_stats* stats,
+static int trace_chunk(rt_scene* s, int form, const rt_params* prm, const float* d_rays, uint32_t n, float* d_rgb, rt_stats* stats,
                        bool* overflow) {
     hipStream_t st = s->stream;
+    // RT_TRAVERSE_PACKET / _SERVE: every level's rays and hits go through that traversal in the per-lane kernels, nothing
+    // is suspended (no quad launches); consecutive caller rays form the packets
+    DScene D = s->d;
+    if (form == RT_TRAVERSE_PACKET) { D.packet = 2; D.user_packet = 1; }
+    const int wide = form == RT_TRAVERSE_SERVE ? RT_FORM_WIDE_SERVE : RT_FORM_WIDE;
     LevelArgs A;
     std::memset(&A, 0, sizeof A);
     A.n0 = n; A.max_depth = prm->max_depth; A.spp = 1;
@@ -1151,23 +1199,23 @@ static int trace_chunk(rt_scene* s, const rt_params* prm, const float* d_rays, u
     launch_set_frame_params(fp, 1, s->d_fp, s->d_counters, sizeof(PassCounters), st);
     A.fp = s->d_fp;
     const int levels = s->has_bounce ? A.max_depth : 0;
-    const bool meshes = s->n_models > 0;
+    const bool meshes = s->n_models > 0 && form == RT_TRAVERSE_QUAD;      // meshes that suspend rays
     const uint32_t gq = std::min<uint32_t>((n + 15) / 16, 4u * RT_LEVEL_GRID);
     // per-lane kernels + resumed queues at every level (level sizes are unknown here), one shade pass over all levels
     for (int lv = 0; lv <= levels; ++lv) {
         A.level = lv; A.level_hi = lv;
-        launch_extend(lv == 0 ? 2 : 1, RT_FORM_WIDE, s->count_work, s->d, A, lv == 0 ? (n + RT_BLOCK - 1) / RT_BLOCK : RT_LEVEL_GRID, st);
-        if (meshes) launch_extend(lv == 0 ? 2 : 1, RT_FORM_QUAD_RESUME, s->count_work, s->d, A, lv == 0 ? gq : 4u * RT_LEVEL_GRID, st);
+        launch_extend(lv == 0 ? 2 : 1, wide, s->count_work, D, A, lv == 0 ? (n + RT_BLOCK - 1) / RT_BLOCK : RT_LEVEL_GRID, st);
+        if (meshes) launch_extend(lv == 0 ? 2 : 1, RT_FORM_QUAD_RESUME, s->count_work, D, A, lv == 0 ? gq : 4u * RT_LEVEL_GRID, st);
     }
     for (int part = 0; part < (levels ? 2 : 1); ++part) {      // level 0 (sample order), then levels 1.. (the sub-pools)
         A.level = part; A.level_hi = part ? levels : 0;
-        launch_shade(RT_FORM_WIDE, s->count_work, s->d, A, part ? RT_LEVEL_GRID : (n + RT_BLOCK - 1) / RT_BLOCK, st);
-        if (meshes) launch_shade(RT_FORM_QUAD_RESUME, s->count_work, s->d, A, 4u * RT_LEVEL_GRID, st);
+        launch_shade(wide, s->count_work, D, A, part ? RT_LEVEL_GRID : (n + RT_BLOCK - 1) / RT_BLOCK, st);
+        if (meshes) launch_shade(RT_FORM_QUAD_RESUME, s->count_work, D, A, 4u * RT_LEVEL_GRID, st);
     }
     if (meshes) {
         for (int lv = 0; lv <= levels; ++lv) {      // the hits of the rays each level parked
             A.level = lv; A.level_hi = lv;
-            launch_shade(RT_FORM_QUAD_PARKED, s->count_work, s->d, A, lv == 0 ? gq : 4u * RT_LEVEL_GRID, st);
+            launch_shade(RT_FORM_QUAD_PARKED, s->count_work, D, A, lv == 0 ? gq : 4u * RT_LEVEL_GRID, st);
         }
     }
     for (int lv = levels - 1; lv >= 1; --lv) { A.level = lv; A.level_hi = lv; launch_fold(s->d, A, 1024, st); }
@@ -1189,7 +1237,13 @@ static int trace_chunk(rt_scene* s, const rt_params* prm, const float* d_rays, u
 }
 
 extern "C" int rt_trace(rt_scene* s, const rt_params* prm, const float* rays, uint32_t n, float* rgb, rt_stats* stats) {
+    return rt_trace_form(s, RT_TRAVERSE_QUAD, prm, rays, n, rgb, stats);
+}
+
+extern "C" int rt_trace_form(rt_scene* s, int form, const rt_params* prm, const float* rays, uint32_t n, float* rgb, rt_stats* stats) {
     if (!s || !prm || !rays || !rgb) { rt_set_error("null argument"); return RT_ERR_INVALID; }
+    if (check_form(form) != RT_OK) return RT_ERR_INVALID;
+    if (s->n_models == 0) form = RT_TRAVERSE_QUAD;      // nothing to traverse: one schedule
     if (prm->max_depth < 0 || prm->max_depth >= RT_MAX_LEVELS) { rt_set_error("max_depth %d outside [0,%d]", prm->max_depth, RT_MAX_LEVELS - 1); return RT_ERR_LIMIT; }
     if (stats) std::memset(stats, 0, sizeof *stats);
     if (n == 0) return RT_OK;
@@ -1204,7 +1258,7 @@ extern "C" int rt_trace(rt_scene* s, const rt_params* prm, const float* rays, ui
     for (uint32_t done = 0; done < n;) {
         const uint32_t cnt = std::min(chunk, n - done);
         bool overflow = false;
-        rc = trace_chunk(s, prm, dr.as<float>() + 6 * size_t(done), cnt, dout.as<float>() + 3 * size_t(done), stats, &overflow);
+        rc = trace_chunk(s, form, prm, dr.as<float>() + 6 * size_t(done), cnt, dout.as<float>() + 3 * size_t(done), stats, &overflow);
         if (rc != RT_OK) return rc;
         if (overflow) {        // the ray trees of this chunk need more pool than it has: halve the chunk and redo it
             if (chunk <= 64) { rt_set_error("bounce queue overflow on a 64-ray chunk"); return RT_ERR_OVERFLOW; }

@@ -1038,10 +1038,11 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(PACKET
     extend_wide_body<SRC, COUNT, PACKET ? 1 : 0>(S, A, nullptr);
 }
 // the rays of a level >= 1, one per lane, meshes by quad service
-template <bool COUNT>
+// (SRC 2: rt_trace_form's caller-supplied rays, for the parity tests)
+template <int SRC, bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WPE_ES))) void k_extend_serve(DScene S, LevelArgs A) {
     __shared__ uint32_t lds_stack[RT_QSTACK * 16];
-    extend_wide_body<1, COUNT, 2>(S, A, lds_stack);
+    extend_wide_body<SRC, COUNT, 2>(S, A, lds_stack);
 }
 
 // k_extend_quad: one ray per quad. FRESH: all rays of the level from the start (levels with few rays: no per-lane
@@ -1504,6 +1505,75 @@ __global__ __launch_bounds__(RT_BLOCK) void k_occluded(DScene S, const float* __
     if (alive && j == 0) occ[i] = in ? 1 : 0;
 }
 
+// The same two unit kernels with one ray per LANE, through the traversal forms the render kernels use for most of
+// their rays: PACKET 1 = the wave's 64 rays walk the tree together (packet_traverse), 2 = quad service
+// (serve_traverse). Rays are taken 64 at a time in the order given, so what a packet holds is the caller's choice
+// (rt_intersect_form / rt_occluded_form: the parity tests feed coherent camera rays AND unrelated random rays).
+template <int PACKET>
+__global__ __launch_bounds__(RT_BLOCK) void k_intersect_lane(DScene S, int object, const float* __restrict__ rays, uint32_t n,
+                                                             int32_t* __restrict__ hit_obj, float* __restrict__ dist_out,
+                                                             float* __restrict__ normal_out) {
+    __shared__ uint32_t lds_stack[RT_QSTACK * 16];
+    const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    const bool alive = i < n;
+    Ray ray;
+    ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 0);
+    if (alive) { ray.o = ld3(rays + 6 * (size_t)i); ray.d = ld3(rays + 6 * (size_t)i + 3); }
+    Work wk = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    HitState h = fresh_hit();
+    float d = 0;
+    V3 nrm = mk(0, 0, 0);
+    int hit = -1;
+    if (object >= 0) {
+        const u32x4 ob = ldc4(S.objects, 2 * object), pb = ldc4(S.objects, 2 * object + 1);
+        const float4 prm = as_f4(pb);
+        bool got = false;
+        if (ob.x == RT_OBJ_SPHERE) { if (alive) got = sphere_isect(prm, __uint_as_float(ob.w), ray, d, nrm); }
+        else if (ob.x == RT_OBJ_PLANE) { if (alive) got = plane_isect(prm, ray, d, nrm); }
+        else {
+            const ModelRef m = load_model(S.models, ob.y);
+            bool need = alive;
+            if (alive) d = FLT_MAX;
+            if (m.bb.w >= 0) need = alive && sphere_gate(m.bb, ray);
+            QuadHit q;
+            q.face = 0xFFFFFFFFu; q.t = 0; q.u = 0; q.v = 0;
+            if (PACKET == 2) serve_traverse<false, false>(S, m.root, need, ray, FLT_MAX, q, lds_stack, wk);
+            else if (__ballot(need)) packet_traverse<false, false>(S, m.root, need, ray, FLT_MAX, q, wk);
+            if (need && q.face != 0xFFFFFFFFu) {
+                const float4* np = reinterpret_cast<const float4*>(S.normals + q.face);
+                d = q.t;
+                nrm = (f4xyz(np[0]) * (1 - q.u - q.v) + f4xyz(np[1]) * q.u) + f4xyz(np[2]) * q.v;
+                got = true;
+            }
+        }
+        if (got) hit = object;
+    } else {
+        closest_loop<false, false, PACKET>(S, ray, alive, 0, h, lds_stack, wk);
+        hit = h.cur; d = h.dist; nrm = h.n;
+    }
+    if (!alive) return;
+    hit_obj[i] = hit;
+    dist_out[i] = d;
+    normal_out[3 * (size_t)i] = nrm.x; normal_out[3 * (size_t)i + 1] = nrm.y; normal_out[3 * (size_t)i + 2] = nrm.z;
+}
+
+template <int PACKET>
+__global__ __launch_bounds__(RT_BLOCK) void k_occluded_lane(DScene S, const float* __restrict__ rays, const float* __restrict__ max_dist,
+                                                            uint32_t n, uint8_t* __restrict__ occ) {
+    __shared__ uint32_t lds_stack[RT_QSTACK * 16];
+    const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
+    const bool alive = i < n;
+    Ray ray;
+    ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 0);
+    float md = 0;
+    if (alive) { ray.o = ld3(rays + 6 * (size_t)i); ray.d = ld3(rays + 6 * (size_t)i + 3); md = max_dist[i]; }
+    Work wk = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float tmp = 0;
+    int sk;
+    const bool in = occluded_loop<false, false, PACKET>(S, ray, alive, 0, md, tmp, sk, lds_stack, wk);
+    if (alive) occ[i] = in ? 1 : 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Launchers (called from rt_api.cpp, which is plain C++)
 // ---------------------------------------------------------------------------------------------------------
@@ -1513,7 +1583,7 @@ template <int SRC>
 static void launch_extend_src(int form, bool count, const DScene& S, const LevelArgs& A, dim3 g, hipStream_t st) {
     dim3 b(RT_BLOCK);
     if (form == RT_FORM_WIDE) {
-        if ((SRC == 0 && S.packet) || (SRC == 1 && S.packet >= 2)) {     // primary rays: coherent, traversed as packets in the per-lane kernel itself (2: experiment, deeper levels too)
+        if ((SRC == 0 && S.packet) || (SRC == 1 && S.packet >= 2) || (SRC == 2 && S.user_packet)) {     // primary rays: coherent, traversed as packets in the per-lane kernel itself (2: deeper levels too; user_packet: rt_trace_form)
             if (count) hipLaunchKernelGGL((k_extend_wide<SRC, true, true>), g, b, 0, st, S, A);
             else hipLaunchKernelGGL((k_extend_wide<SRC, false, true>), g, b, 0, st, S, A);
         } else {
@@ -1521,8 +1591,10 @@ static void launch_extend_src(int form, bool count, const DScene& S, const Level
             else hipLaunchKernelGGL((k_extend_wide<SRC, false, false>), g, b, 0, st, S, A);
         }
     } else if (form == RT_FORM_WIDE_SERVE) {
-        if (count) hipLaunchKernelGGL((k_extend_serve<true>), g, b, 0, st, S, A);
-        else hipLaunchKernelGGL((k_extend_serve<false>), g, b, 0, st, S, A);
+        if constexpr (SRC != 0) {       // (camera rays are never served: level 0 of a frame is packets or marks + quads)
+            if (count) hipLaunchKernelGGL((k_extend_serve<SRC, true>), g, b, 0, st, S, A);
+            else hipLaunchKernelGGL((k_extend_serve<SRC, false>), g, b, 0, st, S, A);
+        }
     } else if (form == RT_FORM_QUAD_FRESH) {
         if (count) hipLaunchKernelGGL((k_extend_quad<SRC, true, true>), g, b, 0, st, S, A);
         else hipLaunchKernelGGL((k_extend_quad<SRC, true, false>), g, b, 0, st, S, A);
@@ -1540,7 +1612,7 @@ template <bool COUNT, bool GPOW>
 static void launch_shade_t(int form, const DScene& S, const LevelArgs& A, dim3 g, dim3 b, hipStream_t st) {
     if (form == RT_FORM_WIDE) {
         // the hits of primary rays: their shadow rays are coherent too (rt_trace's caller-supplied rays need not be)
-        if (S.packet && (A.level == 0 || S.packet >= 2) && !A.user_rays) hipLaunchKernelGGL((k_shade_wide<COUNT, GPOW, true>), g, b, 0, st, S, A);
+        if (S.packet && (A.level == 0 || S.packet >= 2) && (!A.user_rays || S.user_packet)) hipLaunchKernelGGL((k_shade_wide<COUNT, GPOW, true>), g, b, 0, st, S, A);
         else hipLaunchKernelGGL((k_shade_wide<COUNT, GPOW, false>), g, b, 0, st, S, A);
     }
     else if (form == RT_FORM_WIDE_SERVE) hipLaunchKernelGGL((k_shade_serve<COUNT, GPOW>), g, b, 0, st, S, A);
@@ -1583,12 +1655,18 @@ void launch_cast_rays(const DCamera& cam, const float* aa, uint32_t spp, const u
     const uint32_t total = n * spp;
     hipLaunchKernelGGL(k_cast_rays, dim3((total + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, st, cam, aa, spp, xy, n, out);
 }
-void launch_intersect(const DScene& S, int object, const float* rays, uint32_t n, int32_t* hit, float* dist, float* nrm,
+void launch_intersect(const DScene& S, int form, int object, const float* rays, uint32_t n, int32_t* hit, float* dist, float* nrm,
                       hipStream_t st) {
-    hipLaunchKernelGGL(k_intersect, dim3((n + 15) / 16), dim3(RT_BLOCK), 0, st, S, object, rays, n, hit, dist, nrm);
+    const dim3 gl((n + RT_BLOCK - 1) / RT_BLOCK), b(RT_BLOCK);
+    if (form == 1) hipLaunchKernelGGL((k_intersect_lane<1>), gl, b, 0, st, S, object, rays, n, hit, dist, nrm);
+    else if (form == 2) hipLaunchKernelGGL((k_intersect_lane<2>), gl, b, 0, st, S, object, rays, n, hit, dist, nrm);
+    else hipLaunchKernelGGL(k_intersect, dim3((n + 15) / 16), b, 0, st, S, object, rays, n, hit, dist, nrm);
 }
-void launch_occluded(const DScene& S, const float* rays, const float* max_dist, uint32_t n, uint8_t* occ, hipStream_t st) {
-    hipLaunchKernelGGL(k_occluded, dim3((n + 15) / 16), dim3(RT_BLOCK), 0, st, S, rays, max_dist, n, occ);
+void launch_occluded(const DScene& S, int form, const float* rays, const float* max_dist, uint32_t n, uint8_t* occ, hipStream_t st) {
+    const dim3 gl((n + RT_BLOCK - 1) / RT_BLOCK), b(RT_BLOCK);
+    if (form == 1) hipLaunchKernelGGL((k_occluded_lane<1>), gl, b, 0, st, S, rays, max_dist, n, occ);
+    else if (form == 2) hipLaunchKernelGGL((k_occluded_lane<2>), gl, b, 0, st, S, rays, max_dist, n, occ);
+    else hipLaunchKernelGGL(k_occluded, dim3((n + 15) / 16), b, 0, st, S, rays, max_dist, n, occ);
 }
 
 }  // extern "C++"

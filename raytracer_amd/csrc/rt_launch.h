@@ -19,7 +19,7 @@ struct DScene {
     uint32_t debug;              // timing experiments only (RT_DEBUG_SKIP)
     uint32_t generic_pow;        // a material's specRefExp is not an integer in [0, RT_POW_MAX_INT]: shade kernels with pow()
     uint32_t packet;             // level 0 (primary rays and their shadow rays) traverses meshes as 64-ray packets in the per-lane kernels
-    uint32_t pad;
+    uint32_t user_packet;        // rt_trace_form only: caller-supplied rays (SRC 2) and their hits traverse meshes as packets too
     const DModel* models;
     const rt_material* materials;
     const float4* lights;        // 2 per light: pos, color
@@ -141,6 +141,7 @@ void launch_resolve_rgb(const DScene& S, const LevelArgs& A, float* rgb, hipStre
 void launch_untile(const UntileArgs& U, const uint8_t* tiles, uint8_t* out, hipStream_t st);
 void launch_cast_rays(const DCamera& cam, const float* aa, uint32_t spp, const uint32_t* xy, uint32_t n, float* out,
                       hipStream_t st);
-void launch_intersect(const DScene& S, int object, const float* rays, uint32_t n, int32_t* hit, float* dist, float* nrm,
+// form (RT_TRAVERSE_*): 0 one ray per quad, 1 one ray per lane as 64-ray packets, 2 one ray per lane with quad service
+void launch_intersect(const DScene& S, int form, int object, const float* rays, uint32_t n, int32_t* hit, float* dist, float* nrm,
                       hipStream_t st);
-void launch_occluded(const DScene& S, const float* rays, const float* max_dist, uint32_t n, uint8_t* occ, hipStream_t st);
+void launch_occluded(const DScene& S, int form, const float* rays, const float* max_dist, uint32_t n, uint8_t* occ, hipStream_t st);

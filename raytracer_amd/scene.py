@@ -422,30 +422,45 @@ class DeviceScene:
                                                                    C.c_void_p(stream or 0),
                                                                    C.byref(stats) if stats is not None else None))
 
-    def intersect(self, rays, obj=-1):
+    def intersect(self, rays, obj=-1, form=None):
+        """rt_intersect, or rt_intersect_form when `form` (cabi.RT_TRAVERSE_*) is given."""
         rays = cabi.as_f32(rays, (-1, 6))
         n = rays.shape[0]
         hit = np.full(n, -2, np.int32)
         dist = np.zeros(n, np.float32)
         nrm = np.zeros((n, 3), np.float32)
-        cabi.check(self.lib, self.lib.rt_intersect(self.h, obj, fptr(rays), n,
-                                                   hit.ctypes.data_as(C.POINTER(C.c_int32)), fptr(dist), fptr(nrm)))
+        hp = hit.ctypes.data_as(C.POINTER(C.c_int32))
+        if form is None:
+            cabi.check(self.lib, self.lib.rt_intersect(self.h, obj, fptr(rays), n, hp, fptr(dist), fptr(nrm)))
+        else:
+            cabi.check(self.lib, self.lib.rt_intersect_form(self.h, form, obj, fptr(rays), n, hp, fptr(dist), fptr(nrm)))
         return hit, dist, nrm
 
-    def occluded(self, rays, max_dist):
+    def occluded(self, rays, max_dist, form=None):
         rays = cabi.as_f32(rays, (-1, 6))
         md = cabi.as_f32(max_dist, (-1,))
         occ = np.zeros(rays.shape[0], np.uint8)
-        cabi.check(self.lib, self.lib.rt_occluded(self.h, fptr(rays), fptr(md), rays.shape[0], cabi.u8ptr(occ)))
+        if form is None:
+            cabi.check(self.lib, self.lib.rt_occluded(self.h, fptr(rays), fptr(md), rays.shape[0], cabi.u8ptr(occ)))
+        else:
+            cabi.check(self.lib, self.lib.rt_occluded_form(self.h, form, fptr(rays), fptr(md), rays.shape[0], cabi.u8ptr(occ)))
         return occ
 
-    def trace(self, params, rays):
+    def trace(self, params, rays, form=None):
         rays = cabi.as_f32(rays, (-1, 6))
         rgb = np.zeros((rays.shape[0], 3), np.float32)
         st = rt_stats()
-        cabi.check(self.lib, self.lib.rt_trace(self.h, C.byref(params.c), fptr(rays), rays.shape[0], fptr(rgb),
-                                               C.byref(st)))
+        if form is None:
+            cabi.check(self.lib, self.lib.rt_trace(self.h, C.byref(params.c), fptr(rays), rays.shape[0], fptr(rgb),
+                                                   C.byref(st)))
+        else:
+            cabi.check(self.lib, self.lib.rt_trace_form(self.h, form, C.byref(params.c), fptr(rays), rays.shape[0],
+                                                        fptr(rgb), C.byref(st)))
         return rgb, st
+
+    def set_pass_samples(self, samples):
+        """rt_scene_set_pass_samples: level-0 samples per pass (power of two in [2^12, 2^26]; 0 = default)."""
+        cabi.check(self.lib, self.lib.rt_scene_set_pass_samples(self.h, int(samples)))
 
     def bvh_info(self):
         info = cabi.rt_bvh_info()

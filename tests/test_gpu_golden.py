@@ -110,30 +110,117 @@ def test_boundary_errors():
     assert (got == np.array([127, 127, 0], np.uint8)).all() and st.trace_calls == 64 * 48 and st.shadow_rays == 0
 
 
-def test_full_size_properties():
-    """At the bench's size the oracle is too slow for a whole frame; check what does not depend on it:
-    determinism, rectangle decomposition == full frame, ray-count identities, and a sampled strip against the oracle."""
+def _oracle_pixels(O, fs, cam, p, pixels):
+    """render()'s value of single pixels from the oracle's trace() of their samples (reference src/raytracer.cpp:436-448:
+    px += trace(...) / numRays per sample, `/` = multiply by the float reciprocal, color.h:27-30; then B,G,R truncated).
+    For scenes where a ray costs the oracle 0.4 s (10 M faces, every one tested): orc_trace spreads the SAMPLES of a
+    pixel over the host threads, orc_render only spreads rows."""
+    rays = O.cast_rays("orc", cam, p, pixels)                    # (n, spp, 6)
+    rgb, st = O.Oracle(fs).trace(p, rays.reshape(-1, 6))
+    rgb = rgb.reshape(len(pixels), p.spp, 3)
+    inv = np.float32(1) / np.float32(p.spp)
+    px = np.zeros((len(pixels), 3), np.float32)
+    for k in range(p.spp):
+        px = px + rgb[:, k] * inv
+    return (px[:, ::-1] * np.float32(255)).astype(np.uint8), st
+
+
+# workload -> how the oracle checks it: ("frame",) the whole frame; ("rects", [...]) crops through orc_render;
+# ("pixels", [...]) single pixels through orc_trace. Sized to a few CPU-seconds each.
+FULL_SIZE = {
+    "bunny_1080p": ("rects", [(700, 0, 2, 1080)]),                       # a strip through the mesh and the mirror sphere
+    "c2_analytic_1080p_4spp": ("frame",),
+    "c3_bunny_1080p_shadows": ("rects", [(700, 0, 2, 1080)]),
+    "c4_bunny_glass_4k_16spp": ("rects", [(1088, 272, 48, 32), (1580, 1390, 32, 32)]),     # in the glass2 sphere; on the mesh
+    "c5_field_10m_8k_64spp": ("pixels", [(3840, 2721), (2560, 3456), (5000, 3000), (3000, 2400), (4400, 3900), (1200, 2900)]),  # on the blobs of the field
+}
+
+
+@pytest.mark.parametrize("workload", list(FULL_SIZE))
+def test_full_size_properties(workload):
+    """Every BASELINE.json configuration at ITS size (resolution, samples per pixel, depth, triangle count). The oracle
+    is too slow for whole frames there, so: determinism, rectangle decomposition == full frame, ray-count identities,
+    and a sample of the frame against the oracle (bytes within 1 LSB on >= 99.9 %, ray counts equal)."""
     from oracle import oracle as O
-    fs, cam, p = wl.make_workload("bunny_1080p")
+    fs, cam, p = wl.make_workload(workload)
     dev = DeviceScene(fs)
     a, st = dev.render(cam, p)
     b, st2 = dev.render(cam, p)
-    assert np.array_equal(a, b) and st.trace_calls == st2.trace_calls
+    assert np.array_equal(a, b) and st.trace_calls == st2.trace_calls and st.shadow_rays == st2.shadow_rays
     W, H = cam.imWidth, cam.imHeight
-    assert st.level_rays[0] == W * H and st.trace_calls == sum(st.level_rays)
+    assert st.level_rays[0] == W * H * p.spp and st.trace_calls == sum(st.level_rays)
     assert st.shadow_rays % len(fs.lights) == 0 and st.shadow_rays <= len(fs.lights) * st.trace_calls
+    assert st.passes == -(-(W * H) // max(64, (1 << 23) // p.spp)) and st.retries == 0
+    if not any(m.reflective or m.refractive for m in fs.materials):
+        assert st.trace_calls == st.level_rays[0]                       # "shadows only": nothing bounces
     parts = np.zeros_like(a)
     rays = 0
-    for rect in [(0, 0, 1000, 500), (1000, 0, 920, 500), (0, 500, 1920, 580)]:
+    for rect in [(0, 0, W // 2 + 40, H // 2 - 40), (W // 2 + 40, 0, W - (W // 2 + 40), H // 2 - 40), (0, H // 2 - 40, W, H - (H // 2 - 40))]:
         _, s = dev.render(cam, p, rect=rect, out=parts)
         rays += s.trace_calls + s.shadow_rays
     assert np.array_equal(parts, a) and rays == st.trace_calls + st.shadow_rays
-    rect = (700, 0, 2, H)          # a strip through the mesh and the mirror sphere, checked against the oracle
-    want, so = O.Oracle(fs).render(cam, p, rect=rect)
-    x0, y0, w, h = rect
-    d = np.abs(a[y0:y0 + h, x0:x0 + w].astype(np.int16) - want[y0:y0 + h, x0:x0 + w].astype(np.int16)).max(axis=2)
-    print(f"full-size strip: within 1 LSB {(d <= 1).mean():.6f}, equal {(d == 0).mean():.6f}")
+    kind = FULL_SIZE[workload]
+    if kind[0] == "frame":
+        want, so = O.Oracle(fs).render(cam, p, threads=16)
+        d = np.abs(a.astype(np.int16) - want.astype(np.int16)).max(axis=2)
+        assert so.trace_calls == st.trace_calls and so.shadow_rays == st.shadow_rays
+    elif kind[0] == "rects":
+        ds = []
+        for rect in kind[1]:
+            x0, y0, w, h = rect
+            want, so = O.Oracle(fs).render(cam, p, rect=rect, threads=16)
+            _, sg = dev.render(cam, p, rect=rect)
+            assert so.trace_calls == sg.trace_calls and so.shadow_rays == sg.shadow_rays, rect
+            ds.append(np.abs(a[y0:y0 + h, x0:x0 + w].astype(np.int16) - want[y0:y0 + h, x0:x0 + w].astype(np.int16)).max(axis=2).ravel())
+        d = np.concatenate(ds)
+    else:
+        want, so = _oracle_pixels(O, fs, cam, p, kind[1])
+        got = np.stack([a[y, x] for x, y in kind[1]])
+        rays_g = 0
+        for x, y in kind[1]:
+            _, sg = dev.render(cam, p, rect=(x, y, 1, 1))
+            rays_g += sg.trace_calls + sg.shadow_rays
+        assert rays_g == so.trace_calls + so.shadow_rays
+        assert so.trace_calls > len(kind[1]) * p.spp                    # the sampled pixels do hit something that bounces
+        d = np.abs(got.astype(np.int16) - want.astype(np.int16)).max(axis=1)
+    print(f"{workload}: {st.trace_calls}+{st.shadow_rays} rays, {st.passes} passes; oracle sample of {d.size} px: "
+          f"within 1 LSB {(d <= 1).mean():.6f}, equal {(d == 0).mean():.6f}")
     assert (d <= 1).mean() >= 0.999
+
+
+@pytest.mark.parametrize("spp_grid", [1, 2])
+def test_many_passes_equal_one_pass(spp_grid):
+    """The ordinary multi-pass path (a frame of more samples than a pass holds, cut into passes of whole pixels that
+    reuse one workspace) against the oracle and against the same frame in one pass: 2^12-sample passes make a 320x240
+    frame 19 (1 spp) or 75 (4 spp) passes. Synchronous (stats, one stream) and asynchronous (multi-stream) calls."""
+    import torch
+    from oracle import oracle as O
+    fs = wl.scene_bunny(10, third="glass2")
+    cam = reference_camera(320, 240)
+    p = Params(max_depth=6, aa=wl.aa_grid(spp_grid) if spp_grid > 1 else ())
+    dev = DeviceScene(fs)
+    one, st1 = dev.render(cam, p)
+    assert st1.passes == 1
+    dev.set_pass_samples(1 << 12)
+    many, st2 = dev.render(cam, p)
+    assert st2.passes == -(-320 * 240 // ((1 << 12) // p.spp)) and st2.retries == 0
+    assert np.array_equal(one, many)
+    assert (st1.trace_calls, st1.shadow_rays, list(st1.level_rays)) == (st2.trace_calls, st2.shadow_rays, list(st2.level_rays))
+    frame = torch.zeros((240, 320, 3), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(2):
+        dev.render_device(cam, p, frame.data_ptr())
+    dev.status()
+    assert np.array_equal(frame.cpu().numpy(), one)
+    want, so = O.Oracle(fs).render(cam, p, threads=16)
+    d = np.abs(many.astype(np.int16) - want.astype(np.int16)).max(axis=2)
+    assert so.trace_calls == st2.trace_calls and so.shadow_rays == st2.shadow_rays
+    assert (d <= 1).mean() >= 0.999
+    with pytest.raises(cabi.RtError):
+        dev.set_pass_samples(5000)                                        # not a power of two
+    dev.set_pass_samples(0)
+    again, st3 = dev.render(cam, p)
+    assert st3.passes == 1 and np.array_equal(again, one)
 
 
 def test_batch_equals_single_frames():

@@ -76,6 +76,125 @@ def test_occluded_exact(oracle_mod):
     assert np.array_equal(dev.occluded(rays, md), orc.occluded(rays, md))
 
 
+def edge_rays(fs, n_faces, seed):
+    """Rays aimed exactly at shared edges and vertices of the scene's first mesh (edge midpoints, vertices, points a
+    few ulps off an edge), from several origins, unit and non-unit directions: where two or more faces report a hit
+    at the same or nearly the same t and the reference's ascending strict-< scan (src/primitives.cpp:376-382) decides."""
+    rng = np.random.default_rng(seed)
+    m = fs.meshes[0]
+    v0, v1, v2 = m.v[0], m.v[1], m.v[2]
+    f = rng.integers(0, m.num_faces, n_faces)
+    targets = np.concatenate([
+        (v0[f] + v1[f]) * np.float32(0.5), (v1[f] + v2[f]) * np.float32(0.5), (v0[f] + v2[f]) * np.float32(0.5),
+        v0[f], v1[f], v2[f],
+        np.nextafter((v0[f] + v1[f]) * np.float32(0.5), np.float32(np.inf)),
+        v0[f] + (v1[f] - v0[f]) * np.float32(0.25),
+    ]).astype(np.float32)
+    rays = []
+    for o in [(-0.5, 0.0, -0.25), (0.0, 3.0, -7.5), (0.0, 0.0, -1.0), (2.0, -3.0, -2.0)]:
+        o = np.asarray(o, np.float32)
+        d = targets - o
+        rays.append(np.concatenate([np.broadcast_to(o, d.shape), d], axis=1))                       # non-unit
+        dn = (d * (np.float32(1.0) / np.sqrt((d * d).sum(axis=1, keepdims=True)))).astype(np.float32)
+        rays.append(np.concatenate([np.broadcast_to(o, d.shape), dn], axis=1))
+    return np.concatenate(rays).astype(np.float32)
+
+
+def doubled_faces_scene():
+    """A mesh in which every face exists TWICE (and a third time displaced by a few ulps), the copies carrying
+    different vertex normals: the normal that comes back says which face index won the tie."""
+    from raytracer_amd.scene import FlatScene, Mesh, material
+    base = wl.yaml_mesh(6)
+    F = base.num_faces
+    v = [np.concatenate([a, a, a]) for a in base.v[:3]]
+    v[0][2 * F:] = np.nextafter(v[0][2 * F:], np.float32(np.inf))
+    n = [np.concatenate([a, a * np.float32(0.5), a * np.float32(0.25)]) for a in base.v[3:]]
+    perm = np.random.default_rng(5).permutation(3 * F)          # duplicates far apart in face order
+    fs = FlatScene()
+    fs.add_mesh(Mesh(*[a[perm] for a in v], *[a[perm] for a in n], base.bb), material((0.8, 0.8, 0.8)))
+    fs.add_plane((0, 1, 0), 4.0, material((0.5, 0.5, 0.9)))
+    wl.add_yaml_lights(fs)
+    return fs
+
+
+FORMS = [1, 2]      # cabi.RT_TRAVERSE_PACKET, RT_TRAVERSE_SERVE (0, the quads, is what the tests above use)
+
+
+@pytest.mark.parametrize("form", FORMS)
+@pytest.mark.parametrize("scene_name", ["mesh", "doubled", "field"])
+def test_intersect_forms_bit_exact(oracle_mod, scene_name, form):
+    """The traversals that carry most of a frame's rays - 64-ray packets (level 0 and its shadow rays) and quad service
+    (bounce levels of large passes) - against the oracle's brute-force loop, bit for bit: hit object, distance and
+    normal, on coherent camera rays (packets that share their path), unrelated random rays (packets that share
+    nothing), and rays through shared edges, vertices and duplicated faces (ties broken by the lowest face index)."""
+    O = oracle_mod
+    fs = {"mesh": lambda: wl.scene_bunny(12), "doubled": doubled_faces_scene, "field": lambda: wl.scene_field(16, 4)}[scene_name]()
+    dev = DeviceScene(fs)
+    orc = O.Oracle(fs)
+    cam = reference_camera(256, 192)
+    rays = np.concatenate([camera_rays(O, cam, Params(), 1), random_rays(20000, 7), edge_rays(fs, 400, 3)])
+    mesh_obj = [k for k, o in enumerate(fs.objects) if o[0] == 2][0]
+    for obj in (-1, mesh_obj):
+        h2, d2, n2 = orc.intersect(rays, obj)
+        hit = h2 >= 0
+        assert hit.sum() > 1000
+        for f in (0, form):
+            h1, d1, n1 = dev.intersect(rays, obj, form=f)
+            assert np.array_equal(h1, h2), f"form {f} object {obj}: hit/miss differs on {(h1 != h2).sum()} rays"
+            assert np.array_equal(d1[hit].view(np.uint32), d2[hit].view(np.uint32)), f"form {f} object {obj}: dist"
+            assert np.array_equal(n1[hit].view(np.uint32), n2[hit].view(np.uint32)), f"form {f} object {obj}: normal"
+    md = np.random.default_rng(3).uniform(0.1, 30, rays.shape[0]).astype(np.float32)
+    want = orc.occluded(rays, md)
+    assert 0.05 < want.mean() < 0.95
+    assert np.array_equal(dev.occluded(rays, md, form=form), want)
+
+
+@pytest.mark.parametrize("form", FORMS)
+def test_intersections_golden_forms(form):
+    """The reference's own answers (tests/golden/intersect.npz, made by the compiled reference) through packets and
+    quad service."""
+    from helpers import gold, same_bits, sub
+    from raytracer_amd.scene import FlatScene
+    g = gold("intersect.npz")
+    fs = FlatScene.from_arrays(sub(g, "scene_"))
+    dev = DeviceScene(fs)
+    rays = g["rays"]
+    for obj in [-1] + list(range(len(fs.objects))):
+        h, d, n = dev.intersect(rays, obj, form=form)
+        assert np.array_equal(h, g[f"hit_{obj}"]), f"object {obj}: {(h != g[f'hit_{obj}']).sum()} rays differ"
+        hit = h >= 0
+        assert same_bits(d[hit], g[f"dist_{obj}"][hit]) and same_bits(n[hit], g[f"normal_{obj}"][hit])
+    assert np.array_equal(dev.occluded(rays, g["max_dist"], form=form), g["occluded"])
+    lone = DeviceScene(FlatScene.from_arrays(sub(g, "lone_")))
+    h, d, n = lone.intersect(rays, -1, form=form)
+    assert np.array_equal(h, g["lone_hit"])
+    hit = h >= 0
+    assert same_bits(d[hit], g["lone_dist"][hit]) and same_bits(n[hit], g["lone_normal"][hit])
+
+
+@pytest.mark.parametrize("form", FORMS)
+@pytest.mark.parametrize("third,depth", [("glass2", 10), ("glass", 3)])
+def test_trace_colours_forms(oracle_mod, third, depth, form):
+    """trace() with every level's rays and shadow rays through packets / quad service: float colours and per-level ray
+    counts against the oracle's recursion (same bar as test_trace_colours)."""
+    O = oracle_mod
+    fs = wl.scene_bunny(8, third=third)
+    dev = DeviceScene(fs)
+    cam = reference_camera(200, 150)
+    p = Params(max_depth=depth)
+    rays = camera_rays(O, cam, p, 1)
+    got, st1 = dev.trace(p, rays, form=form)
+    want, st2 = O.Oracle(fs).trace(p, rays)
+    assert st1.trace_calls == st2.trace_calls and st1.shadow_rays == st2.shadow_rays
+    assert list(st1.level_rays) == list(st2.level_rays)
+    same = (got.view(np.uint32) == want.view(np.uint32)).all(axis=1).mean()
+    print(f"trace form {form} {third} depth {depth}: bit-equal colours {same:.6f}, max abs diff {np.abs(got - want).max():.3g}")
+    assert np.abs(got - want).max() <= 2e-6
+    assert same >= 0.999
+    quad, _ = dev.trace(p, rays)
+    assert np.array_equal(got.view(np.uint32), quad.view(np.uint32))      # the device forms agree to the bit (same pow)
+
+
 @pytest.mark.parametrize("third,depth", [("glass", 10), ("glass2", 10), ("glass2", 1), ("glass2", 0), ("glass2", 8)])
 def test_trace_colours(oracle_mod, third, depth):
     O = oracle_mod
