@@ -163,6 +163,23 @@ int rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_params* par
                      uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
                      uint8_t* d_bgr_out, void* stream, rt_stats* stats);
 
+/* rt_render_device for callers that CANNOT ALLOCATE (code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc). No counterpart in the reference. Same kernels and schedule, asynchronous on `stream` (NULL: the
+ * scene's own), same bytes as rt_render_device; but the frame's node pool is not the scene's grow-only hipMalloc'ed
+ * workspace, it is a fixed 20.5 MiB array that is part of the library's device image (one copy per GPU the library runs
+ * on, held until the process ends), used in passes of 2^14 samples (12 pool entries per sample). The call performs no hipMalloc, hipFree or other
+ * allocating call. Limits: the rectangle (rounded up to multiples of 8 in each direction) times the samples per pixel
+ * must not exceed RT_NOALLOC_MAX_SAMPLES (2^21: a 1920x1080 frame at 1 sample per pixel fits), else RT_ERR_LIMIT.
+ * Every call on one GPU - whatever the rt_scene - shares that GPU's array: calls that overlap on one GPU race; order
+ * them on one stream or wait for the previous one. A frame whose ray trees outgrow the pool is reported by
+ * rt_scene_status (RT_ERR_OVERFLOW) as for every asynchronous call: render it again, the scene has switched to passes
+ * a quarter the size (4x the room per sample, down to 64-pixel passes; a scene that still overflows there needs
+ * rt_render_device, whose pool can grow). */
+#define RT_NOALLOC_MAX_SAMPLES (1u << 21)
+int rt_render_device_noalloc(rt_scene* scene, const rt_camera* cam, const rt_params* params,
+                             uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
+                             uint8_t* d_bgr_out, void* stream);
+
 /* A BATCH of frames in one call: n_frames (1..32) frames of the same size, scene and params that differ only in
  * their cameras (an animation's consecutive frames, or the steps of a benchmark). Frame b is written
  * frame_stride_bytes * b behind d_bgr_out. Every launch then works on n_frames times as many rays: a small frame - or

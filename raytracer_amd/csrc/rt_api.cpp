@@ -118,6 +118,7 @@ struct rt_scene {
     hipStream_t last_stream = nullptr;   // stream of the most recent asynchronous frame
     uint32_t last_spp = 1;
     uint32_t ws_min_n0 = 0;              // the workspace is sized for at least this many samples per pass (grown after overflows)
+    void* noalloc_ws = nullptr;          // this device's copy of the file-scope `scratch` array (rt_render_device_noalloc)
     uint32_t pass_samples = 1u << 23;    // level-0 samples per pass (frames with more are cut into passes of whole pixels)
 };
 #define RT_PASS_SAMPLES (s->pass_samples)
@@ -269,6 +270,13 @@ extern "C" int rt_scene_create_ex(const rt_flat_scene* sc, int device, uint32_t 
     if (const char* e = std::getenv("RT_PACKET")) { s->d.packet = sc->n_models > 0 ? uint32_t(std::atoi(e)) : 0u; s->packet_auto = false; }
     s->d.user_packet = 0;
     s->pass_samples = default_pass_samples();
+    // set-up for rt_render_device_noalloc: the address of the static workspace ON THIS DEVICE (current since hipSetDevice
+    // above), asked once per device and kept; the entry point itself then allocates and looks up nothing
+    if (hipError_t e = noalloc_scratch(device, &s->noalloc_ws); e != hipSuccess) {
+        rt_set_error("hipGetSymbolAddress(scratch) failed on device %d: %s", device, hipGetErrorString(e));
+        return fail(RT_ERR_DEVICE);
+    }
+    s->aa_cache.reserve(2 * RT_MAX_AA_POINTS);      // so that a new anti-aliasing pattern never allocates
     if ((rc = upload(s, objs.data(), objs.size(), &s->d.objects)) != RT_OK) return fail(rc);
     if ((rc = upload(s, models.data(), models.size(), &s->d.models)) != RT_OK) return fail(rc);
     if ((rc = upload(s, sc->materials, size_t(sc->n_materials), &s->d.materials)) != RT_OK) return fail(rc);
@@ -571,7 +579,7 @@ static uint32_t wide_grid_for(const rt_scene* s, uint32_t pass, int lo, int hi) 
 // kernel's duration is its own.
 struct PassRec { uint64_t px0; uint32_t npx; uint32_t slot; };
 
-static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass_px, std::vector<PassRec>& recs) {
+static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass_px, std::vector<PassRec>* recs) {
     rt_scene* s = J.s;
     const uint32_t spp = J.base.spp;
     const bool meshes = s->n_models > 0;
@@ -737,7 +745,7 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
         HIP_TRY(hipGetLastError());
         // level sizes of this pass -> scheduling hint of the next one (no sync; see h_hint)
         HIP_TRY(hipMemcpyAsync(s->h_hint + size_t(slot) * RT_SHARDS, pc->sc, sizeof(ShardCounters) * RT_SHARDS, hipMemcpyDeviceToHost, sa));
-        recs.push_back({px0 + done, cnt, slot});
+        if (recs) recs->push_back({px0 + done, cnt, slot});
     }
     return RT_OK;
 }
@@ -751,8 +759,10 @@ static void learn_from_overflow(rt_scene* s, uint32_t full_px) {
 
 // Renders n_frames frames that differ only in their cameras (cam[0..n_frames)) as ONE sample range: frame b's pixels
 // follow frame b-1's, frame b's output starts b * out_stride bytes behind d_out.
+// noalloc: the workspace is the static array of rt_kernels.hip (a pass of RT_NOALLOC_PASS_SAMPLES), nothing is
+// allocated, grown or freed; asynchronous only.
 static int render_frame(rt_scene* s, const rt_camera* cam, uint32_t n_frames, const rt_params* prm, const PixelMap& pm,
-                        uint8_t* d_out, uint64_t out_stride, hipStream_t st, rt_stats* stats, bool sync) {
+                        uint8_t* d_out, uint64_t out_stride, hipStream_t st, rt_stats* stats, bool sync, bool noalloc = false) {
     HIP_TRY(hipSetDevice(s->device));
     const uint32_t spp = 1 + prm->n_aa;
     const uint64_t frame_px = uint64_t(pm.n_owned) * pm.tile_w * pm.tile_h;
@@ -766,8 +776,16 @@ static int render_frame(rt_scene* s, const rt_camera* cam, uint32_t n_frames, co
     if (*s->h_overflow && s->last_overflow == -1) { s->last_overflow = 1; learn_from_overflow(s, full_px); }
     uint32_t pass_px = uint32_t(std::min<uint64_t>(total_px, std::max<uint32_t>(64u, full_px >> s->shrink_log2)));
     pass_px = (pass_px + 63u) & ~63u;
-    int rc = ensure_workspace(s, std::max(((uint32_t(std::min<uint64_t>(total_px, full_px)) + 63u) & ~63u) * spp, s->ws_min_n0));
-    if (rc != RT_OK) return rc;
+    int rc = RT_OK;
+    if (noalloc) {
+        // whole pixels, a multiple of 64 of them, within the static pool (rounded DOWN; 64 pixels of <= 256 samples fit)
+        const uint32_t fit_px = std::max<uint32_t>(64u, ((RT_NOALLOC_PASS_SAMPLES / spp) >> s->shrink_log2) & ~63u);
+        pass_px = uint32_t(std::min<uint64_t>((total_px + 63u) & ~63ull, fit_px));
+        if (uint64_t(pass_px) * spp > RT_NOALLOC_PASS_SAMPLES) { rt_set_error("64 pixels of %u samples do not fit the static workspace", spp); return RT_ERR_LIMIT; }
+    } else {
+        rc = ensure_workspace(s, std::max(((uint32_t(std::min<uint64_t>(total_px, full_px)) + 63u) & ~63u) * spp, s->ws_min_n0));
+        if (rc != RT_OK) return rc;
+    }
 
     // Packets below level 0 too (the large levels' per-lane kernels) when a 64-entry block holds the children of few
     // pixels, i.e. at 16+ samples per pixel: measured 1426 -> 844 ms (level 0) -> 791 ms (all levels) per frame on the 10 M-
@@ -780,10 +798,22 @@ static int render_frame(rt_scene* s, const rt_camera* cam, uint32_t n_frames, co
     B.max_depth = prm->max_depth;
     B.spp = spp;
     B.sub_cap = s->sub_cap;
+    B.rays = s->rays; B.node_a = s->node_a; B.node_b = s->node_b; B.hit_n = s->hit_n; B.hit_p = s->hit_p; B.queue_e = s->queue_e; B.queue_s = s->queue_s;
+    if (noalloc) {      // the same arrays, carved out of this device's static workspace
+        unsigned char* w = static_cast<unsigned char*>(s->noalloc_ws);
+        const size_t cap = RT_NOALLOC_CAP;
+        B.node_a = reinterpret_cast<float4*>(w); w += cap * sizeof(float4);
+        B.node_b = reinterpret_cast<uint4*>(w);  w += cap * sizeof(uint4);
+        B.hit_n = reinterpret_cast<float4*>(w);  w += cap * sizeof(float4);
+        B.hit_p = reinterpret_cast<float4*>(w);  w += cap * sizeof(float4);
+        B.queue_e = reinterpret_cast<uint2*>(w); w += cap * sizeof(uint2);
+        B.queue_s = reinterpret_cast<uint2*>(w); w += cap * sizeof(uint2);
+        B.rays = reinterpret_cast<float4*>(w);
+        B.sub_cap = s->has_bounce ? (RT_NOALLOC_CAP - RT_NOALLOC_PASS_SAMPLES) / RT_SHARDS : 0u;
+    }
     B.chunk_log2 = RT_SHARD_CHUNK_LOG2;
     if (const char* e = std::getenv("RT_CHUNK_LOG2")) B.chunk_log2 = std::min<uint32_t>(uint32_t(std::atoi(e)), RT_SHARD_CHUNK_LOG2_MAX);   // experiments
     if (const char* dbg = std::getenv("RT_DEBUG_SKIP")) { B.debug = uint32_t(std::atoi(dbg)); s->d.debug = B.debug; }   // timing experiments only
-    B.rays = s->rays; B.node_a = s->node_a; B.node_b = s->node_b; B.hit_n = s->hit_n; B.hit_p = s->hit_p; B.queue_e = s->queue_e; B.queue_s = s->queue_s;
     B.aa = s->d_aa;
     B.fp = s->d_fp;
     B.pm = pm;
@@ -825,7 +855,7 @@ static int render_frame(rt_scene* s, const rt_camera* cam, uint32_t n_frames, co
         std::memset(&key, 0, sizeof key);
         key.base = B; key.d_out = d_out; key.total_px = total_px; key.pass_px = pass_px; key.large_mask = J.large_mask;
         key.count = s->count_work; key.debug = s->d.debug;
-        if (s->graph_ok && !no_graph && !s->count_work) {
+        if (s->graph_ok && !no_graph && !s->count_work && !noalloc) {
             for (size_t g = 0; g < s->graphs.size(); ++g)
                 if (std::memcmp(&key, &s->graphs[g].key, sizeof key) == 0) {
                     rt_scene::CachedGraph cg = s->graphs[g];
@@ -840,7 +870,7 @@ static int render_frame(rt_scene* s, const rt_camera* cam, uint32_t n_frames, co
                 hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
                 int crc = RT_OK;
                 if (hipMemsetAsync(s->d_counters, 0, counter_bytes, st) != hipSuccess) crc = RT_ERR_DEVICE;
-                if (crc == RT_OK) crc = enqueue_passes(J, 0, total_px, pass_px, recs);
+                if (crc == RT_OK) crc = enqueue_passes(J, 0, total_px, pass_px, nullptr);
                 hipGraph_t graph = nullptr;
                 const hipError_t ee = hipStreamEndCapture(st, &graph);
                 hipGraphExec_t exec = nullptr;
@@ -859,15 +889,14 @@ static int render_frame(rt_scene* s, const rt_camera* cam, uint32_t n_frames, co
                 (void)hipGetLastError();
                 s->graph_ok = false;            // this runtime cannot capture the schedule: launch directly from now on
                 if (crc != RT_OK && crc != RT_ERR_DEVICE) return crc;
-                recs.clear();
                 J.n_pass_used = 0; J.n_timed = 0;
             }
         }
-        return enqueue_passes(J, 0, total_px, pass_px, recs);
+        return enqueue_passes(J, 0, total_px, pass_px, nullptr);
     }
 
     if (stats) HIP_TRY(hipEventRecord(s->ev_begin, st));
-    rc = enqueue_passes(J, 0, total_px, pass_px, recs);
+    rc = enqueue_passes(J, 0, total_px, pass_px, &recs);
     if (rc != RT_OK) return rc;
 
     // Synchronous: read the counters back, re-run overflowed passes at half the size until they fit.
@@ -908,7 +937,7 @@ static int render_frame(rt_scene* s, const rt_camera* cam, uint32_t n_frames, co
             const uint32_t n_new = (r.npx + part - 1) / part;
             if (J.n_pass_used + n_new > RT_MAX_PASSES) { rt_set_error("out of pass slots while retrying"); return RT_ERR_OVERFLOW; }
             HIP_TRY(hipMemsetAsync(s->d_counters + J.n_pass_used, 0, sizeof(PassCounters) * n_new, st));
-            rc = enqueue_passes(J, r.px0, r.npx, part, recs);
+            rc = enqueue_passes(J, r.px0, r.npx, part, &recs);
             if (rc != RT_OK) return rc;
             // remember it: the next frames of this scene start with passes that fit
             uint32_t lg = 0;
@@ -999,6 +1028,26 @@ extern "C" int rt_render_batch_device(rt_scene* s, const rt_camera* cams, uint32
 extern "C" int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_params* prm, uint32_t x0, uint32_t y0,
                                 uint32_t w, uint32_t h, uint8_t* d_bgr, void* stream, rt_stats* stats) {
     return rt_render_batch_device(s, cam, 1, prm, x0, y0, w, h, d_bgr, 0, stream, stats);
+}
+
+// rt_render_device for callers that cannot allocate: same kernels, same schedule, the node pool in the static array.
+// No hipMalloc / hipFree / stream or event creation here or below (render_frame with noalloc: no ensure_workspace, no
+// graph cache, no pass records); everything else it touches was created by rt_scene_create.
+extern "C" int rt_render_device_noalloc(rt_scene* s, const rt_camera* cam, const rt_params* prm, uint32_t x0, uint32_t y0,
+                                        uint32_t w, uint32_t h, uint8_t* d_bgr, void* stream) {
+    if (!s || !d_bgr) { rt_set_error("null argument"); return RT_ERR_INVALID; }
+    int rc = check_params(cam, prm);
+    if (rc != RT_OK) return rc;
+    if ((rc = check_rect(cam, x0, y0, w, h)) != RT_OK) return rc;
+    if (!s->noalloc_ws) { rt_set_error("the static workspace was not set up for device %d", s->device); return RT_ERR_DEVICE; }
+    const uint64_t samples = uint64_t((w + 7u) & ~7u) * ((h + 7u) & ~7u) * (1u + prm->n_aa);
+    if (samples > RT_NOALLOC_MAX_SAMPLES) {
+        rt_set_error("rt_render_device_noalloc: %llu samples (rectangle rounded up to multiples of 8, times %u samples per pixel) "
+                     "above the maximum %u; use rt_render_device", (unsigned long long)samples, 1u + prm->n_aa, RT_NOALLOC_MAX_SAMPLES);
+        return RT_ERR_LIMIT;
+    }
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : s->stream;
+    return render_frame(s, cam, 1, prm, rect_map(cam, x0, y0, w, h), d_bgr, 0, st, nullptr, false, true);
 }
 
 extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_params* prm, uint32_t x0, uint32_t y0, uint32_t w,

@@ -1575,6 +1575,38 @@ __global__ __launch_bounds__(RT_BLOCK) void k_occluded_lane(DScene S, const floa
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Workspace of rt_render_device_noalloc (include/raytracer_amd.h): for callers that cannot allocate, the node pool of
+// one small pass lives in this file-scope array instead of hipMalloc'ed memory. Every GPU the library runs on holds
+// its own copy (20.5 MiB) at its own address until the process ends. `scratch` as host code sees it is a stand-in, not
+// a device address: host code only ever uses the pointer hipGetSymbolAddress returned for the device in question,
+// and the kernels get it as an argument (the LevelArgs pool pointers), exactly as they get hipMalloc'ed memory.
+// ---------------------------------------------------------------------------------------------------------
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES];
+
+#include <mutex>
+#define RT_NOALLOC_MAX_DEVICES 64
+hipError_t noalloc_scratch(int device, void** ptr) {
+    static std::mutex mu;
+    static void* per_device[RT_NOALLOC_MAX_DEVICES] = {};
+    *ptr = nullptr;
+    if (device < 0 || device >= RT_NOALLOC_MAX_DEVICES) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!per_device[device]) {
+        int cur = -1;
+        hipError_t e = hipGetDevice(&cur);
+        if (e != hipSuccess) return e;
+        if (cur != device) return hipErrorInvalidDevice;      // the symbol's address is per device: ask with that device current
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!p) return hipErrorInvalidSymbol;
+        per_device[device] = p;
+    }
+    *ptr = per_device[device];
+    return hipSuccess;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Launchers (called from rt_api.cpp, which is plain C++)
 // ---------------------------------------------------------------------------------------------------------
 extern "C++" {

@@ -127,6 +127,19 @@ struct UntileArgs {
     uint64_t out_stride;    // batch: bytes between consecutive output frames
 };
 
+// ---- rt_render_device_noalloc: the frame workspace in a file-scope __device__ array (rt_kernels.hip: `scratch`) ----
+// One pass of RT_NOALLOC_PASS_SAMPLES level-0 samples with TWICE the ordinary pool factor (a small pass can lie entirely on
+// a glass sphere, where the ray trees are largest; the ordinary factor is an average over millions of samples): node_a,
+// node_b, hit_n, hit_p (16 B per pool entry each), queue_e, queue_s (8 B each), rays (32 B per entry behind level 0)
+// = 20.5 MiB.
+#define RT_NOALLOC_PASS_SAMPLES (1u << 14)
+#define RT_NOALLOC_POOL_FACTOR 12u
+#define RT_NOALLOC_CAP (RT_NOALLOC_PASS_SAMPLES * RT_NOALLOC_POOL_FACTOR)
+#define RT_NOALLOC_SCRATCH_BYTES (size_t(RT_NOALLOC_CAP) * (4u * 16u + 2u * 8u) + size_t(RT_NOALLOC_CAP - RT_NOALLOC_PASS_SAMPLES) * 32u)
+// Device address of `scratch` on `device` (which must be the current device): hipGetSymbolAddress once per device,
+// remembered. Returns hipSuccess or the error.
+hipError_t noalloc_scratch(int device, void** ptr);
+
 // Kernel forms: one ray per lane (suspends at meshes), one ray per quad from the start, one per quad resuming the queue.
 // RT_FORM_QUAD_PARKED (shade only): one hit per quad from the start, for the rays of the level's extend queue.
 // RT_FORM_WIDE_SERVE (levels >= 1): one ray / hit per lane like RT_FORM_WIDE, but nothing is suspended: the lanes whose ray

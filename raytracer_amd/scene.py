@@ -400,6 +400,13 @@ class DeviceScene:
                                                        C.c_void_p(d_ptr), C.c_void_p(stream or 0),
                                                        C.byref(stats) if stats is not None else None))
 
+    def render_device_noalloc(self, cam, params, d_ptr, rect=None, stream=None):
+        """rt_render_device_noalloc: rt_render_device without any allocation (static 20 MiB workspace, <= 2^21 samples)."""
+        W, H = cam.imWidth, cam.imHeight
+        x0, y0, w, h = rect if rect is not None else (0, 0, W, H)
+        cabi.check(self.lib, self.lib.rt_render_device_noalloc(self.h, C.byref(cam), C.byref(params.c), x0, y0, w, h,
+                                                               C.c_void_p(d_ptr), C.c_void_p(stream or 0)))
+
     def render_tiles_device(self, cam, params, tile, part, n_parts, d_ptr, stream=None, stats=None):
         cabi.check(self.lib, self.lib.rt_render_tiles_device(self.h, C.byref(cam), C.byref(params.c), tile[0],
                                                              tile[1], part, n_parts, C.c_void_p(d_ptr),
