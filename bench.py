@@ -3,20 +3,35 @@
 
 A "step" is one full frame of the workload (default: the reference's scene.yaml "bunny scene" at 1920x1080 with
 its own reflective materials, depth 10, 1 ray per pixel; the mesh is the 69,620-face procedural stand-in for
-bun_zipper.ply, which does not ship with the reference). The scene is resident in HBM before the timed region;
-the frame stays in HBM (device framebuffer).
+bun_zipper.ply, which does not ship with the reference). The scene is resident in HBM before the timed region.
 
-N = 1: rt_render_device renders the whole frame.
-N > 1: strong scaling of the same frame. 32x32-pixel tiles are dealt round-robin to the ranks (scene replicated),
-       each rank renders its tiles with rt_render_tiles_device, the tile buffers are gathered to rank 0 with
-       torch.distributed (backend nccl = RCCL over xGMI) and rank 0 scatters them into the row-major frame.
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (child
+processes, before anything touches a GPU) and relays rank 0's JSON line; under torch.distributed.run the ranks are
+already there and WORLD_SIZE must equal --gpus.
 
+N = 1: rt_render_batch_device renders whole frames into a device framebuffer.
+N > 1: strong scaling of the same frames. 32x32-pixel tiles are dealt round-robin to the ranks (scene replicated;
+       the reference's own model is the tile pool of src/raytracer.cpp:583-617), each rank renders its tiles, the
+       tile buffers are gathered to rank 0 with torch.distributed (backend nccl = RCCL over xGMI) and rank 0 scatters
+       them into the row-major frames.
+
+What the JSON line's times are:
+  value / ms_per_step / ms_per_frame_batched_throughput   K frames, device framebuffer, batches of B frames with
+        DIFFERENT cameras per call, two calls in flight: whole-job throughput with everything resident in HBM
+  ms_per_frame          SURVEY.md 8(d) to the letter: wall time of one synchronous rt_render of the full image into a
+                        HOST buffer (D2H included), median of >= 10 frames after 2 warm-ups
+  ms_per_frame_latency  one rt_render_device call + wait, device framebuffer (median)
+  ms_per_frame_host     frames delivered to page-locked HOST memory by the pipelined path
+                        (rt_render_batch_host_async, two scenes alternating: the copy of one call overlaps the next)
 Rays = trace() invocations + shadow rays, counted on the device.
 """
 import argparse
 import ctypes as C
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,23 +39,79 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s
-VALU_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: FP32 vector peak
+VALU_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: FP32 vector peak (= 1024 SIMDs x 2.4 GHz x 64 lanes x 2 / 2 cycles)
+SIMDS, CLOCK_GHZ = 1024, 2.4
+# A wave64 VALU instruction issues in 2 cycles on a CDNA4 SIMD-32 (cdna_hip_programming.md section 1); measured with
+# tools/valu_rate.hip: v_fma/v_mul/v_add reach that with several waves per SIMD, v_min/v_max/v_cmp/v_cndmask/DPP/
+# v_readlane take 4, v_rcp/v_sqrt 8 (profiles/r2/valu_rate.txt). The peak below is the 2-cycle rate.
+VALU_ISSUE_PEAK_GINST = SIMDS * CLOCK_GHZ / 2.0
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=32)
+    ap.add_argument("--workload", default="bunny_1080p")
+    ap.add_argument("--tile", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="only the timed run: no latency/host/roofline/CPU legs")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal only: every rank uses GPU 0 (needs --backend gloo)")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="library calls in flight (each in its own scene workspace and stream); 0 = 2, or 1 when one frame is several passes already")
+    ap.add_argument("--frames-per-batch", type=int, default=32,
+                    help="frames (steps) rendered per library call, rt_render_batch_device: every launch then carries "
+                         "that many frames' rays (1..32; 1 = one call per frame)")
+    ap.add_argument("--same-camera", action="store_true", help="experiments: every frame of a batch from the reference camera")
+    ap.add_argument("--bvh", default="host", choices=("host", "device"),
+                    help="BVH builder: the host's SAH tree (default) or the GPU's linear BVH (RT_SCENE_BVH_DEVICE)")
+    ap.add_argument("--rehearse-exchange", action="store_true",
+                    help="rehearsal only: a 1-rank job (launched through torch.distributed.run) takes the N-rank path - tiles, "
+                         "RCCL gather to itself, untile - so that the exchange code runs on the real backend with one GPU")
+    ap.add_argument("--rehearse-launcher", action="store_true",
+                    help="rehearsal only (no GPU needed): the ranks rendezvous, all-gather their ranks and rank 0 prints "
+                         "what it saw; checks that --gpus N really is N processes")
+    ap.add_argument("--watchdog", type=int, default=0, help="dump all Python stacks and exit after this many seconds")
+    return ap.parse_args()
+
+
+def launch_ranks(args):
+    """--gpus N without a launcher: N child processes of this script, one per GPU, rendezvous on 127.0.0.1. The parent
+    never touches a GPU (no re-exec of a process that has). Rank 0's stdout is relayed; exit code = the worst child's."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    bad = [c for c in codes if c != 0]
+    sys.exit(bad[0] if bad else 0)
 
 
 def algorithmic_work(work, rays, closest_rays, n_lights):
     """bytes/ray = B_node N_node + 48 N_tri + 16 N_sphere + 16 N_plane + 48 with B_node = 128 (one
     4-wide node = 4 child boxes, i.e. two of the survey's 64-B two-box nodes);
-    flops/ray = 96 N_node + 47 N_tri + 35 N_sphere + 13 N_plane + S (S = 17 + 60 per light for closest-hit rays)."""
-    b = 128 * work.nodes_visited + 48 * work.tris_tested + 16 * work.spheres_tested + 16 * work.planes_tested + 48 * rays
-    f = (96 * work.nodes_visited + 47 * work.tris_tested + 35 * work.spheres_tested + 13 * work.planes_tested
+    flops/ray = 96 N_node + 47 N_tri + 35 N_sphere + 13 N_plane + S (S = 17 + 60 per light for closest-hit rays).
+    N_* must be PER-RAY counts (a scene created with RT_SCENE_NO_PACKETS: every ray traversed by itself)."""
+    b = 128 * work["nodes"] + 48 * work["tris"] + 16 * work["spheres"] + 16 * work["planes"] + 48 * rays
+    f = (96 * work["nodes"] + 47 * work["tris"] + 35 * work["spheres"] + 13 * work["planes"]
          + closest_rays * (17 + 60 * n_lights))
     return b, f
 
 
 def cpu_baseline(fs, cam, params, dev, np):
     """The reference's own objects (oracle/_ref, kind 'reference') or the C restatement ('port') on a bounded sample:
-    8 full-height strips, 4 pixels wide, evenly spread over the frame (rows under OpenMP schedule(dynamic,10) as the
-    reference's render())."""
+    8 full-height strips, evenly spread over the frame (rows under OpenMP schedule(dynamic,10) as the reference's
+    render())."""
     from oracle import oracle as O
     kind = "reference" if O.have_ref() else "port"
     cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("OMP_NUM_THREADS", "16")), 16)
@@ -63,10 +134,10 @@ def cpu_baseline(fs, cam, params, dev, np):
 
     if fs.num_faces > 1000000:
         # the reference tests EVERY face per ray (src/primitives.cpp:376-382): at 10 M faces a few thousand rays are all
-        # that fit the time bound, so the sample is one 6x6 crop on the middle of the field at 1 sample per pixel
+        # that fit the time bound, so the sample is one 16x16 crop on the middle of the field at 1 sample per pixel
         from raytracer_amd.scene import Params
         p1 = Params(background=tuple(params.c.background), max_depth=params.c.max_depth, aa=())
-        rect = (W // 2 - 3, int(0.63 * H) - 3, 6, 6)
+        rect = (W // 2 - 8, int(0.63 * H) - 8, 16, 16)
         g, st = dev.render(cam, p1, rect=rect)
         t = time.time()
         c, _ = backend.render(cam, p1, rect=rect, threads=cores)
@@ -75,57 +146,60 @@ def cpu_baseline(fs, cam, params, dev, np):
         d = np.abs(g[y0:y0 + h, x0:x0 + w].astype(np.int16) - c[y0:y0 + h, x0:x0 + w].astype(np.int16)).max(axis=2)
         rays = st.trace_calls + st.shadow_rays
         return {"value": rays / secs / 1e6, "unit": "Mrays/s", "cores": cores, "kind": kind,
-                "sample": f"6x6 px crop on the middle of the field at 1 spp ({rays} rays, {secs:.1f} s CPU wall)",
+                "sample": f"16x16 px crop on the middle of the field at 1 spp ({rays} rays, {secs:.1f} s CPU wall)",
                 "gpu_matches_cpu_on_sample": bool(float((d <= 1).mean()) >= 0.999)}
     width = 4
     rays, secs, same = run(width)                    # probe, then size the sample to about 15 s of CPU wall time
     target = int(width * 15.0 / max(secs, 1e-3))
     if target > width:
-        width = max(4, min(W // 8, 160, target))
+        width = max(4, min(W // 8, target))
         rays, secs, same = run(width)
     return {"value": rays / secs / 1e6, "unit": "Mrays/s", "cores": cores, "kind": kind,
             "sample": f"8 strips of {width}x{H} px of the same frame, evenly spread ({rays} rays, {secs:.1f} s CPU wall)",
             "gpu_matches_cpu_on_sample": bool(same)}
 
 
+def median(xs):
+    xs = sorted(xs)
+    n = len(xs)
+    return xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2])
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=128)
-    ap.add_argument("--warmup", type=int, default=32)
-    ap.add_argument("--workload", default="bunny_1080p")
-    ap.add_argument("--tile", type=int, default=32)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
-    ap.add_argument("--single-device", action="store_true",
-                    help="rehearsal only: every rank uses GPU 0 (needs --backend gloo)")
-    ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="library calls in flight (each in its own scene workspace and stream); 0 = 2, or 1 when one frame is several passes already")
-    ap.add_argument("--frames-per-batch", type=int, default=32,
-                    help="frames (steps) rendered per library call, rt_render_batch_device: every launch then carries "
-                         "that many frames' rays (1..32; 1 = one call per frame)")
-    ap.add_argument("--bvh", default="host", choices=("host", "device"),
-                    help="BVH builder: the host's SAH tree (default) or the GPU's linear BVH (RT_SCENE_BVH_DEVICE)")
-    ap.add_argument("--rehearse-exchange", action="store_true",
-                    help="rehearsal only: a 1-rank job (launched through torch.distributed.run) takes the N-rank path - tiles, "
-                         "RCCL gather to itself, untile - so that the exchange code runs on the real backend with one GPU")
-    ap.add_argument("--watchdog", type=int, default=0, help="dump all Python stacks and exit after this many seconds")
-    args = ap.parse_args()
+    args = parse_args()
     if args.watchdog:
         import faulthandler
         faulthandler.dump_traceback_later(args.watchdog, exit=True)
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        launch_ranks(args)                           # does not return
+    world = int(env_world or "1")
+    if world != args.gpus and not args.rehearse_exchange:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}, "
+                         f"or without a launcher (bench.py then starts the ranks itself)\n")
+        sys.exit(2)
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
 
     import numpy as np
     import torch
     import torch.distributed as dist
 
+    if args.rehearse_launcher:
+        dist.init_process_group("gloo")
+        seen = [None] * world
+        dist.all_gather_object(seen, (rank, os.getpid()))
+        if rank == 0:
+            print(json.dumps({"rehearse_launcher": True, "n_gpus": args.gpus, "rccl_ranks": dist.get_world_size(),
+                              "ranks_seen": sorted(r for r, _ in seen), "distinct_processes": len({p for _, p in seen})}), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+
     from raytracer_amd import cabi, workloads as wl
     from raytracer_amd.cabi import rt_stats
-    from raytracer_amd.scene import DeviceScene
+    from raytracer_amd.scene import DeviceScene, Params
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
     if args.single_device:
@@ -157,7 +231,7 @@ def main():
     # that leave most of the chip idle, and a small frame - or one rank's share of a frame - is bound by the host's
     # launch rate. So (1) the steps are rendered B frames per library call (rt_render_batch_device: the frames' rays share
     # every launch) and (2) two calls are in flight, each with its own scene workspace, stream and framebuffers. Every
-    # frame is still rendered completely and compared with the census frame below.
+    # frame is still rendered completely and compared with its camera's census frame below.
     # ... as many as fill about one 8 M-sample pass of this rank (a batch of large frames would only add passes)
     # a frame of several 8 M-sample passes fills the chip by itself: a second call in flight only competes for the caches
     # (4K 16 spp glass scene: 55 ms one call at a time, 67 ms with two)
@@ -165,7 +239,8 @@ def main():
     # ... and at least two calls per slot inside the timed region, so that the exchange of one call (gather, untile)
     # overlaps the rendering of the next whatever --steps is
     B = max(1, min(32, args.frames_per_batch, (8 << 20) // max(1, (W * H * params.spp) // world), args.steps // (2 * in_flight)))
-    cams = [cam] * B
+    # the frames of a batch are DIFFERENT pictures: camera k on a small circle through the reference camera (camera 0)
+    cams = [cam] * B if args.same_camera else wl.orbit_cameras(W, H, B)
     frame_bytes = H * W * 3
 
     class Slot:
@@ -186,20 +261,26 @@ def main():
             sl.allt = torch.zeros((world * B * sl.part_bytes,), dtype=torch.uint8, device="cuda") if rank == 0 else None
             sl.gathered = list(sl.allt.chunk(world)) if rank == 0 else None     # the gather lands directly in the untile input
         slots.append(sl)
+    torch.cuda.synchronize()       # the fills above ran on torch's stream, the renders run on the scenes' own
     stream = slots[0].stream.cuda_stream
     frame = slots[0].frame
 
-    # ray census of one frame (untimed), with the traversal work counters on
+    # ray census (untimed): one frame per camera of the batch, each kept as that camera's reference frame
     st = rt_stats()
-    work_k = None
+    cam_rays, ref_frames = [], []
     if rank == 0:
-        dev.set_count_work(True)
-        dev.render_device(cam, params, frame.data_ptr(), stream=stream, stats=st)
-        work_k = [dev.get_work(k) for k in range(5)]
-        work_hits = st.shadow_rays // max(len(fs.lights), 1)      # shaded hits (each shoots one ray per light)
-        dev.set_count_work(False)
-        ref_frame = frame.clone()
-    rays_per_frame = st.trace_calls + st.shadow_rays
+        for k in range(B):
+            if k and args.same_camera:
+                cam_rays.append(cam_rays[0]); ref_frames.append(ref_frames[0])
+                continue
+            sk = rt_stats()
+            dev.render_device(cams[k], params, frame.data_ptr(), stream=stream, stats=sk)
+            cam_rays.append(sk.trace_calls + sk.shadow_rays)
+            ref_frames.append(frame.clone())
+            if k == 0:
+                st = sk
+        torch.cuda.synchronize()
+    rays_per_frame = st.trace_calls + st.shadow_rays       # of the reference camera
 
     def step(i, b=1):
         """Call number i: the next b (<= B) frames, on slot i % slots."""
@@ -228,13 +309,15 @@ def main():
                                                            C.c_void_p(sl.frames.data_ptr()), C.c_void_p(h)))
 
     def run_steps(n):
-        """n frames as ceil(n / B) calls."""
-        done, call = 0, 0
+        """n frames as ceil(n / B) calls; returns the rays of those frames (rank 0 knows them)."""
+        done, call, rays = 0, 0, 0
         while done < n:
             b = min(B, n - done)
             step(call, b)
+            rays += sum(cam_rays[:b]) if cam_rays else 0
             done += b
             call += 1
+        return rays
 
     def sync():
         if multi and "barrier" not in os.environ.get("BENCH_SKIP", ""):
@@ -263,164 +346,232 @@ def main():
         sync()
         if not overflowed():
             break
+    sync()
     t = time.perf_counter()
-    run_steps(args.steps)
+    timed_rays = run_steps(args.steps)
     sync()
     elapsed = time.perf_counter() - t
     if overflowed():
         raise SystemExit("bench.py: a timed frame ran out of ray pool; the measurement is void")
-    if multi and "barrier" not in os.environ.get("BENCH_SKIP", ""):
-        e = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(e, op=dist.ReduceOp.MAX)
-        elapsed = float(e.item())
+    rccl_ranks = 1
+    if multi:
+        rccl_ranks = dist.get_world_size()
+        if "barrier" not in os.environ.get("BENCH_SKIP", ""):
+            e = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(e, op=dist.ReduceOp.MAX)
+            elapsed = float(e.item())
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         out = {
-            "metric": "Mrays/s", "value": rays_per_frame * args.steps / elapsed / 1e6, "unit": "Mrays/s",
+            "metric": "Mrays/s", "value": timed_rays / elapsed / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-            "ms_per_frame": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "ms_per_frame_batched_throughput": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic", "rccl_ranks": rccl_ranks,
             "config": {"workload": args.workload, "width": W, "height": H, "spp": params.spp,
                        "max_depth": params.c.max_depth, "triangles": fs.num_faces, "objects": len(fs.objects),
                        "lights": len(fs.lights), "rays_per_frame": rays_per_frame,
+                       "rays_per_frame_by_camera": cam_rays,
                        "trace_calls": st.trace_calls, "shadow_rays": st.shadow_rays,
                        "level_rays": [int(x) for x in st.level_rays[:params.c.max_depth + 1]],
                        "parallelism": "1 GPU" if world == 1 else f"{world} GPUs: {tw}x{th} tiles round-robin, RCCL gather",
                        "mesh": "procedural geodesic blob (no .ply ships with the reference)",
                        "scene_build_s": round(build_s, 3), "bvh": args.bvh,
-                       "bvh_build_s": round(dev.bvh_info().build_seconds, 4)},
+                       "bvh_build_s": round(dev.bvh_info().build_seconds, 4),
+                       "cameras": "reference camera" if args.same_camera else
+                                  f"{B} per batch: the reference camera and {B - 1} on a circle of radius 0.05 through it",
+                       "value_is": "device-framebuffer throughput of batched frames (K steps / wall time of the timed region)"},
         }
-        identical = all(bool(torch.equal(sl.frames[k], ref_frame)) for sl in slots for k in range(sl.last_b))
+        identical = all(bool(torch.equal(sl.frames[k], ref_frames[k])) for sl in slots for k in range(sl.last_b))
         out["frame_identical_to_1gpu"] = identical
         out["config"]["frames_in_flight"] = len(slots)
         out["config"]["frames_per_batch"] = B
         out["config"]["pool_adapt_rounds"] = adapt_rounds
-        if not multi and (len(slots) > 1 or B > 1):
-            # latency view: the same frames one at a time (one workspace, one stream)
-            t = time.perf_counter()
-            for _ in range(args.steps):
-                with torch.cuda.stream(slots[0].stream):
-                    dev.render_device(cam, params, frame.data_ptr(), stream=stream)
-            torch.cuda.synchronize()
-            out["one_frame_at_a_time"] = {"ms_per_frame": (time.perf_counter() - t) / args.steps * 1e3}
-        if not multi:
-            # The frame's time is in four kernels: k_extend_wide / k_extend_quad (closest hits: analytic objects one ray
-            # per lane, meshes one ray per quad) and k_shade_wide / k_shade_quad (shadow rays + Phong). A call with stats
-            # runs them back to back on ONE stream with HIP events around every launch (the untimed path overlaps the
-            # shade kernels with deeper extend launches, which would blur per-kernel durations).
-            reps = 10 if W * H * params.spp <= 64 << 20 else 2      # a stats call times at most 2048 launches of a frame
-            names = ("k_extend_wide", "k_shade_wide", "k_extend_quad", "k_shade_quad<0|1>", "k_shade_quad<2>")
-            NK = len(names)
-            ms = [0.0] * NK
-            n = [0] * NK
-            frame_ms = 0.0
-            for _ in range(reps):
-                s2 = rt_stats()
-                dev.render_device(cam, params, frame.data_ptr(), stream=stream, stats=s2)
-                for k in range(NK):
-                    ms[k] += s2.kernel_ms_by[k]; n[k] += s2.kernel_launches_by[k]
-                frame_ms += s2.kernel_ms
-            per_kernel = {}
-            for ki, name in enumerate(names):
-                if not n[ki]:
-                    continue
-                wk = work_k[ki]
-                # rays whose record the kernel reads or writes (48 B each in the survey's formula): a wide kernel sees
-                # every ray of its kind, a quad kernel the rays it traverses (16 per batch at most)
-                rays_k = (st.trace_calls if ki == 0 else st.shadow_rays) if ki < 2 else min(16 * wk.batches, st.trace_calls if ki == 2 else st.shadow_rays)
-                b, f = algorithmic_work(wk, rays_k, work_hits if ki == 1 else 0, len(fs.lights))
-                lp = n[ki] / reps
-                avg = ms[ki] / n[ki]
-                per_kernel[name] = {
-                    "avg_launch_ms": avg, "launches_per_frame": lp, "ms_per_frame_serial": ms[ki] / reps,
-                    "algorithmic_bytes_per_launch": b / lp, "GB/s": b / lp / (avg * 1e-3) / 1e9,
-                    "TFLOP/s": f / lp / (avg * 1e-3) / 1e12,
-                    "work_per_frame": {"bvh_nodes": wk.nodes_visited, "tri_tests": wk.tris_tested,
-                                       "sphere_tests": wk.spheres_tested, "plane_tests": wk.planes_tested,
-                                       "wave_node_steps": wk.wave_node_steps, "wave_tri_steps": wk.wave_tri_steps,
-                                       "batches": wk.batches}}
-            # HBM bytes per launch from the PMC passes of tools/exp_traffic.sh (FETCH_SIZE x2 + WRITE_SIZE, separate runs;
-            # committed under profiles/r*/traffic_<workload>.json). bench.py cannot collect counters itself.
-            import glob
-            traffic = {}
-            tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"traffic_{args.workload}.json")))
-            if tf:
-                traffic = {k: v["hbm_bytes_per_launch"] for k, v in json.load(open(tf[-1]))["kernels"].items()}
-            for name in per_kernel:     # all launches of the kernel, whatever its template arguments
-                tot = [(v, json.load(open(tf[-1]))["kernels"][k]["launches"]) for k, v in traffic.items() if k.split("<")[0] == name] if tf else []
-                per_kernel[name]["hbm_bytes_per_launch_pmc"] = (sum(v * l for v, l in tot) / sum(l for _, l in tot)) if tot else None
-            # Roofline of the dominant LAUNCH: a frame at max_depth 0 runs exactly the level-0 launches (the heaviest of
-            # the frame), so its counters and its HIP-event durations belong to single launches, which rocprofv3 lists
-            # under the same templated names.
-            from raytracer_amd.scene import Params
-            p0 = Params(background=tuple(params.c.background), max_depth=0, aa=params.aa)
-            dev.set_count_work(True)
-            s0 = rt_stats()
-            dev.render_device(cam, p0, frame.data_ptr(), stream=stream, stats=s0)
-            work0 = [dev.get_work(k) for k in range(NK)]
-            dev.set_count_work(False)
-            ms0, n0 = [0.0] * NK, [0] * NK
-            for _ in range(reps):
-                s2 = rt_stats()
-                dev.render_device(cam, p0, frame.data_ptr(), stream=stream, stats=s2)
-                for k in range(NK):
-                    ms0[k] += s2.kernel_ms_by[k]; n0[k] += s2.kernel_launches_by[k]
-            dev.render_device(cam, params, frame.data_ptr(), stream=stream)      # leave the full frame in the buffer
-            torch.cuda.synchronize()
-            # (a scene whose level 0 is traversed as packets has no quad launches at level 0: the per-lane kernels'
-            # PACKET instantiations do the whole level)
-            pk = "true" if (fs.num_faces and not n0[2]) else "false"
-            rocprof_names = (f"k_extend_wide<0, false, {pk}>", f"k_shade_wide<false, false, {pk}>", "k_extend_quad<0, false, false>",
-                             "k_shade_quad<1, false, false>", "k_shade_quad<2, false, false>")
-            dk = max(range(NK), key=lambda k: ms0[k] / max(n0[k], 1))
-            avg = ms0[dk] / n0[dk]
-            lp = n0[dk] / reps
-            rays_k = (s0.trace_calls if dk == 0 else s0.shadow_rays) if dk < 2 else min(16 * work0[dk].batches, s0.trace_calls if dk == 2 else s0.shadow_rays)
-            b, f = algorithmic_work(work0[dk], rays_k, s0.shadow_rays // max(len(fs.lights), 1) if dk == 1 else 0, len(fs.lights))
-            gbs, tfl = b / lp / (avg * 1e-3) / 1e9, f / lp / (avg * 1e-3) / 1e12
-            out["roofline"] = {
-                "bound": "hbm", "kernel": rocprof_names[dk], "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": gbs / HBM_PEAK_GBS, "traffic": traffic.get(rocprof_names[dk]),
-                "avg_launch_ms": avg, "launches_per_frame": lp, "algorithmic_bytes_per_launch": b / lp,
-                "units_per_launch": {"rays": rays_k, "bvh_nodes": work0[dk].nodes_visited, "tri_tests": work0[dk].tris_tested,
-                                     "sphere_tests": work0[dk].spheres_tested, "plane_tests": work0[dk].planes_tested},
-                "valu": {"achieved": tfl, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / VALU_PEAK_TFLOPS},
-                "level0_launch_ms": {rocprof_names[k]: ms0[k] / n0[k] for k in range(NK) if n0[k]},
-                "serial_frame_ms": frame_ms / reps, "kernels": per_kernel,
-            }
-            # What the launch really moves over HBM (PMC bytes / the same duration). `achieved` follows SURVEY.md 8d to
-            # the letter: every node a RAY visits is priced at 128 B. A packet fetches a node once for its 64 rays,
-            # through the scalar cache, and the trees of this workload live in L2, so `frac` can exceed 1: those bytes
-            # never reach HBM and the HBM roofline does not bind the kernel.
-            tr = traffic.get(rocprof_names[dk])
-            if tr:
-                rate = tr / (avg * 1e-3) / 1e9
-                out["roofline"]["hbm_measured"] = {"achieved": rate, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rate / HBM_PEAK_GBS}
-            # What does bind the frame: VALU issue. SQ_INSTS_VALU of all launches of one frame (PMC pass committed under
-            # profiles/, tools/exp_pmc_sq.sh) x 4 cycles per wave64 instruction / (1024 SIMDs x 2.4 GHz), against the
-            # measured time per frame.
-            pf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"pmc_sq_{args.workload}.json")))
-            if pf:
-                n_valu = json.load(open(pf[-1]))["valu_instructions_per_frame"]
-                busy_ms = n_valu * 4 / (1024 * 2.4e9) * 1e3
-                out["roofline"]["valu_issue"] = {"valu_instructions_per_frame": n_valu, "cycles_per_instruction": 4, "simds": 1024,
-                                                 "clock_GHz": 2.4, "busy_ms_per_frame": busy_ms, "frac": busy_ms / out["ms_per_step"]}
-            # the boundary as the reference has it (rt_render: host framebuffer, synchronous): PCIe-inclusive, never `value`
-            host_frame = np.zeros((H, W, 3), np.uint8)
-            dev.render(cam, params, out=host_frame, want_stats=False)
-            t = time.perf_counter()
-            for _ in range(5):
-                dev.render(cam, params, out=host_frame, want_stats=False)
-            host_ms = (time.perf_counter() - t) / 5 * 1e3
-            out["host_framebuffer"] = {"ms_per_frame": host_ms, "Mrays/s": rays_per_frame / host_ms / 1e3,
-                                       "note": "rt_render into a host buffer (frame copied over PCIe, call synchronous)"}
-            if not args.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline(fs, cam, params, dev, np)
+        if not multi and not args.no_extras:
+            extras(args, out, dev, slots, fs, cam, cams, params, st, rays_per_frame, cam_rays, ref_frames, np, torch)
         print(json.dumps(out), flush=True)
     if multi:
         dist.barrier(device_ids=[local]) if args.backend == "nccl" else dist.barrier()
         dist.destroy_process_group()
+
+
+def extras(args, out, dev, slots, fs, cam, cams, params, st, rays_per_frame, cam_rays, ref_frames, np, torch):
+    """One GPU only: latency and host-framebuffer figures, per-kernel table, roofline, CPU baseline."""
+    from raytracer_amd.cabi import rt_stats
+    from raytracer_amd.scene import DeviceScene, Params
+    W, H = cam.imWidth, cam.imHeight
+    B = len(cams)
+    frame_bytes = H * W * 3
+    stream = slots[0].stream.cuda_stream
+    frame = slots[0].frame
+    big = W * H * params.spp > (64 << 20)           # seconds per frame: fewer repetitions
+    n_lat = 3 if big else 12
+
+    # ---- latency: one call, one frame, wait (device framebuffer) ----
+    ts = []
+    for k in range(n_lat + 2):
+        t = time.perf_counter()
+        dev.render_device(cam, params, frame.data_ptr(), stream=stream)
+        dev.status()
+        ts.append((time.perf_counter() - t) * 1e3)
+    out["ms_per_frame_latency"] = median(ts[2:])
+    # ---- SURVEY.md 8(d) to the letter: synchronous rt_render of the full image into a host buffer ----
+    pinned = torch.empty((max(B, 1), H, W, 3), dtype=torch.uint8).pin_memory()
+    host_frame = pinned[0].numpy()
+    ts = []
+    for k in range(n_lat + 2):
+        t = time.perf_counter()
+        dev.render(cam, params, out=host_frame, want_stats=False)
+        ts.append((time.perf_counter() - t) * 1e3)
+    out["ms_per_frame"] = median(ts[2:])
+    host_ok = bool(np.array_equal(host_frame, ref_frames[0].cpu().numpy()))
+    pageable = np.zeros((H, W, 3), np.uint8)
+    ts = []
+    for k in range(min(n_lat, 5) + 1):
+        t = time.perf_counter()
+        dev.render(cam, params, out=pageable, want_stats=False)
+        ts.append((time.perf_counter() - t) * 1e3)
+    # ---- pipelined host delivery: batches into page-locked memory, the copy of one call under the next call's kernels ----
+    # (ONE scene: it renders into two device buffers in turn and copies on a stream of its own, so call n+1's kernels run
+    # over call n's copy. Two scenes alternating were measured slower, 0.44 against 0.41 ms per frame, three 0.51: their
+    # ten streams share the process's four hardware queues; tools/exp_host_pipe.py)
+    pins = [pinned, torch.empty((B, H, W, 3), dtype=torch.uint8).pin_memory()]
+    n_host = max(4 * B, min(args.steps, 64 if not big else 2 * B))
+
+    def host_steps(n):
+        done, call, rays = 0, 0, 0
+        while done < n:
+            b = min(B, n - done)
+            dev.render_batch_host_async(cams[:b], params, pins[call % 2].data_ptr(), frame_bytes)
+            rays += sum(cam_rays[:b])
+            done += b
+            call += 1
+        return rays
+    host_steps(4 * B)
+    for sl in slots:
+        sl.dev.status()
+    t = time.perf_counter()
+    host_rays = host_steps(n_host)
+    for sl in slots:
+        sl.dev.status()
+    host_el = time.perf_counter() - t
+    out["ms_per_frame_host"] = host_el / n_host * 1e3
+    host_ok = host_ok and all(bool(np.array_equal(pins[0][k].numpy(), ref_frames[k].cpu().numpy())) for k in range(B))
+    out["host_framebuffer"] = {
+        "ms_per_frame_pipelined": out["ms_per_frame_host"], "Mrays/s_pipelined": host_rays / host_el / 1e6, "frames": n_host,
+        "ms_per_frame_sync_pinned": out["ms_per_frame"], "ms_per_frame_sync_pageable": median(ts[1:]),
+        "frames_identical_to_device_frames": host_ok,
+        "note": "PCIe-inclusive, never `value`: pipelined = rt_render_batch_host_async into page-locked memory, calls "
+                "alternating on the scenes in flight; sync = rt_render, one frame per call, wall time of the call"}
+
+    # ---- per-kernel table of one frame: launches back to back on ONE stream with HIP events around each ----
+    reps = 10 if not big else 2      # a stats call times at most 2048 launches of a frame
+    names = ("k_extend_wide", "k_shade_wide", "k_extend_quad", "k_shade_quad<0|1>", "k_shade_quad<2>")
+    NK = len(names)
+
+    def timed_frames(prm, n):
+        ms, cnt, total = [0.0] * NK, [0] * NK, 0.0
+        for _ in range(n):
+            s2 = rt_stats()
+            dev.render_device(cam, prm, frame.data_ptr(), stream=stream, stats=s2)
+            for k in range(NK):
+                ms[k] += s2.kernel_ms_by[k]; cnt[k] += s2.kernel_launches_by[k]
+            total += s2.kernel_ms
+        return ms, cnt, total
+    ms, n, frame_ms = timed_frames(params, reps)
+    per_kernel = {names[k]: {"avg_launch_ms": ms[k] / n[k], "launches_per_frame": n[k] / reps, "ms_per_frame_serial": ms[k] / reps}
+                  for k in range(NK) if n[k]}
+
+    # ---- roofline of the dominant LAUNCH. A frame at max_depth 0 runs exactly the level-0 launches (the heaviest of
+    # the frame), one per kernel: HIP-event durations, work counters and PMC counters there belong to single launches,
+    # which rocprofv3 lists under the same templated names. ----
+    p0 = Params(background=tuple(params.c.background), max_depth=0, aa=params.aa)
+    ms0, n0, _ = timed_frames(p0, reps)
+    # per-RAY algorithmic work (SURVEY.md 8d: the nodes / triangles each ray's OWN traversal visits): the same depth-0
+    # frame on a scene that never forms packets, with the counting kernels. Extend work = kinds 0 + 2, shade = 1 + 3 + 4.
+    devq = DeviceScene(fs, device=dev.device, bvh=args.bvh, packets=False)
+    devq.set_count_work(True)
+    s0 = rt_stats()
+    devq.render_device(cam, p0, frame.data_ptr(), stats=s0)
+    wq = [devq.get_work(k) for k in range(NK)]
+    devq.close()
+    # what the packets do instead: node / triangle steps per WAVE (one scalar fetch serves 64 rays)
+    dev.set_count_work(True)
+    sp = rt_stats()
+    dev.render_device(cam, p0, frame.data_ptr(), stream=stream, stats=sp)
+    wp = [dev.get_work(k) for k in range(NK)]
+    dev.set_count_work(False)
+    dev.render_device(cam, params, frame.data_ptr(), stream=stream)      # leave the full frame in the buffer
+    dev.status()
+
+    def summed(ws):
+        return {"nodes": sum(w.nodes_visited for w in ws), "tris": sum(w.tris_tested for w in ws),
+                "spheres": sum(w.spheres_tested for w in ws), "planes": sum(w.planes_tested for w in ws)}
+    per_ray = {0: summed([wq[0], wq[2]]), 1: summed([wq[1], wq[3], wq[4]])}
+    # (a scene whose level 0 is traversed as packets has no quad launches at level 0: the per-lane kernels'
+    # PACKET instantiations do the whole level)
+    pk = "true" if (fs.num_faces and not n0[2]) else "false"
+    rocprof_names = (f"k_extend_wide<0, false, {pk}>", f"k_shade_wide<false, false, {pk}>", "k_extend_quad<0, false, false>",
+                     "k_shade_quad<1, false, false>", "k_shade_quad<2, false, false>")
+    dk = max(range(2), key=lambda k: ms0[k] / max(n0[k], 1))      # level 0 = the two per-lane launches
+    avg_ms = ms0[dk] / n0[dk]
+    rays_k = s0.trace_calls if dk == 0 else s0.shadow_rays
+    hits = s0.shadow_rays // max(len(fs.lights), 1)
+    b_alg, f_alg = algorithmic_work(per_ray[dk], rays_k, hits if dk == 1 else 0, len(fs.lights))
+    # PMC counters of the same launch, collected by tools/collect_counters.sh (bench.py cannot run rocprofv3 on itself)
+    ctr_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"counters_{args.workload}.json")))
+    ctr, ctr_src = None, None
+    if ctr_files:
+        cj = json.load(open(ctr_files[-1]))
+        ctr = cj.get("depth0", {}).get(rocprof_names[dk])
+        ctr_src = {"file": os.path.relpath(ctr_files[-1], ROOT), "commit": cj.get("commit"), "kernel": rocprof_names[dk],
+                   "note": "counters come from this committed file, durations and work counts are measured live"}
+    roof = {"kernel": rocprof_names[dk], "avg_launch_ms": avg_ms, "launches_per_frame_at_depth0": n0[dk] / reps,
+            "units_per_launch": dict(per_ray[dk], rays=rays_k,
+                                     note="per RAY: each ray traversed by itself (RT_SCENE_NO_PACKETS census of the same frame)"),
+            "packet_steps_per_launch": {"wave_node_steps": wp[dk].wave_node_steps, "wave_tri_steps": wp[dk].wave_tri_steps,
+                                        "lane_node_visits": wp[dk].nodes_visited, "lane_tri_tests": wp[dk].tris_tested,
+                                        "note": "what the launch executes: one scalar fetch and one step per WAVE for its 64 rays"},
+            "level0_launch_ms": {rocprof_names[k]: ms0[k] / n0[k] for k in range(NK) if n0[k]},
+            "serial_frame_ms": frame_ms / reps, "kernels": per_kernel, "counters_from": ctr_src}
+    alg_gbs = b_alg / (avg_ms * 1e-3) / 1e9
+    alg_tfl = f_alg / (avg_ms * 1e-3) / 1e12
+    roof["algorithmic"] = {"bytes_per_launch": b_alg, "GB/s": alg_gbs, "of_hbm_peak": alg_gbs / HBM_PEAK_GBS,
+                           "flops_per_launch": f_alg, "TFLOP/s": alg_tfl, "of_valu_peak": alg_tfl / VALU_PEAK_TFLOPS,
+                           "note": "SURVEY.md 8(d) formulas x per-ray counts / launch duration. Nodes, leaves and the object "
+                                   "table are served by L2 and the scalar cache (see traffic), so the byte rate is not an HBM rate"}
+    traffic = ctr["hbm_bytes"] if ctr else None
+    hbm_heavy = traffic is not None and traffic / (avg_ms * 1e-3) / 1e9 > 0.4 * HBM_PEAK_GBS
+    if ctr and not hbm_heavy:
+        # what binds a launch whose working set lives in L2: instruction issue
+        ginst = ctr["SQ_INSTS_VALU"] / (avg_ms * 1e-3) / 1e9
+        roof.update({"bound": "valu_issue", "achieved": ginst, "peak": VALU_ISSUE_PEAK_GINST, "unit": "G wave64-instructions/s",
+                     "frac": ginst / VALU_ISSUE_PEAK_GINST, "traffic": traffic,
+                     "valu_instructions_per_launch": ctr["SQ_INSTS_VALU"], "salu_instructions_per_launch": ctr.get("SQ_INSTS_SALU"),
+                     "valu_pipe_busy_4cycle": ctr["SQ_INSTS_VALU"] * 4 / (SIMDS * CLOCK_GHZ * 1e9 * avg_ms * 1e-3),
+                     "wait_inst_share_of_wave_cycles": ctr.get("SQ_WAIT_INST_ANY", 0) / max(ctr.get("SQ_WAVE_CYCLES", 1), 1),
+                     "wait_any_share_of_wave_cycles": ctr.get("SQ_WAIT_ANY", 0) / max(ctr.get("SQ_WAVE_CYCLES", 1), 1),
+                     "l2_hit_rate": ctr.get("TCC_HIT_sum", 0) / max(ctr.get("TCC_HIT_sum", 0) + ctr.get("TCC_MISS_sum", 0), 1),
+                     "note": "peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (SIMD-32; equals the 157.3 TFLOP/s "
+                             "FMA peak); valu_pipe_busy_4cycle prices every instruction at 4 cycles, which is what min/max/"
+                             "compare/select/DPP/readlane cost on this chip (tools/valu_rate.hip)"})
+    elif ctr:
+        rate = traffic / (avg_ms * 1e-3) / 1e9
+        roof.update({"bound": "hbm", "achieved": rate, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rate / HBM_PEAK_GBS,
+                     "traffic": traffic, "note": "achieved = measured HBM bytes (2 x FETCH_SIZE + WRITE_SIZE) / launch duration"})
+    else:
+        # no counter file for this workload: the algorithmic byte rate, capped by what the formula can mean
+        roof.update({"bound": "hbm", "achieved": alg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": min(alg_gbs / HBM_PEAK_GBS, 1.0), "traffic": None,
+                     "note": "no profiles/r*/counters_<workload>.json: algorithmic bytes only; frac is capped at 1 because "
+                             "cache-served bytes can exceed what HBM could deliver"})
+    if ctr:
+        roof["hbm_measured"] = {"bytes_per_launch": traffic, "GB/s": traffic / (avg_ms * 1e-3) / 1e9,
+                                "of_hbm_peak": traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    out["roofline"] = roof
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(fs, cam, params, dev, np)
+        out["vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
 
 
 if __name__ == "__main__":

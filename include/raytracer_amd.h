@@ -145,6 +145,11 @@ int rt_scene_create(const rt_flat_scene* scene, int device, rt_scene** out);
  * whose tree would be too deep for the traversal stack silently gets the host builder). Results are the same with
  * either tree. No counterpart in the reference. */
 #define RT_SCENE_BVH_DEVICE 1u
+/* RT_SCENE_NO_PACKETS: every mesh ray is traversed by itself (one ray per quad of lanes), never as part of a 64-ray
+ * packet. Same results, slower frames; with rt_set_count_work the work counters are then per RAY (the nodes and
+ * triangles that ray's own traversal needs: SURVEY.md section 8d's N_node / N_tri), which is what bench.py's
+ * algorithmic bytes are computed from. */
+#define RT_SCENE_NO_PACKETS 2u
 int rt_scene_create_ex(const rt_flat_scene* scene, int device, uint32_t flags, rt_scene** out);
 void rt_scene_destroy(rt_scene* scene);
 
@@ -194,6 +199,21 @@ int rt_render_batch_device(rt_scene* scene, const rt_camera* cams, uint32_t n_fr
 int rt_render_tiles_batch_device(rt_scene* scene, const rt_camera* cams, uint32_t n_frames, const rt_params* params,
                                  uint32_t tile_w, uint32_t tile_h, uint32_t part, uint32_t n_parts,
                                  uint8_t* d_tiles_out, uint64_t frame_stride_bytes, void* stream, rt_stats* stats);
+
+/* Replaces: a loop of render() calls whose `img` is a HOST buffer (reference src/raytracer.cpp:434,446-448,666-667),
+ * without blocking: the frames (n_frames cameras, as rt_render_batch_device) are rendered into a device buffer the scene
+ * owns and copied into host_bgr_out (frame b at + b * frame_stride_bytes, the reference's full-image BGR8 layout, only
+ * the rectangle written) by a copy on a stream of the scene's own, ordered behind the rendering on `stream` (NULL: the scene's own). The call
+ * returns at once; the bytes are valid after rt_scene_status(scene) - NOT after a wait on `stream` alone. With PAGE-LOCKED host memory
+ * (rt_pinned_alloc, hipHostMalloc, hipHostRegister) the copy overlaps the kernels of the next call on another scene:
+ * two scenes alternating deliver host frames at nearly the device-framebuffer rate. Pageable memory works, slower. */
+int rt_render_batch_host_async(rt_scene* scene, const rt_camera* cams, uint32_t n_frames, const rt_params* params,
+                               uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
+                               uint8_t* host_bgr_out, uint64_t frame_stride_bytes, void* stream);
+/* Page-locked host memory for framebuffers (hipHostMalloc / hipHostFree). No counterpart in the reference (its img is
+ * a plain array, src/raytracer.cpp:666). */
+int rt_pinned_alloc(size_t bytes, void** out);
+void rt_pinned_free(void* p);
 
 /* Waits for the scene's outstanding asynchronous frames and says whether they are good: RT_OK, or RT_ERR_OVERFLOW
  * when one of them ran out of the pool that holds the child rays (a scene whose ray trees branch more than the

@@ -12,6 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "librt_amd.so")
 
 RT_SCENE_BVH_DEVICE = 1
+RT_SCENE_NO_PACKETS = 2
 RT_OBJ_SPHERE, RT_OBJ_PLANE, RT_OBJ_MODEL = 0, 1, 2
 RT_TRAVERSE_QUAD, RT_TRAVERSE_PACKET, RT_TRAVERSE_SERVE = 0, 1, 2
 
@@ -107,7 +108,7 @@ def u8ptr(a):
 # Every symbol include/raytracer_amd.h declares; tests check the library exports all of them.
 EXPORTS = [
     "rt_scene_create", "rt_scene_create_ex", "rt_scene_destroy", "rt_render", "rt_render_device", "rt_render_tiles_device",
-    "rt_render_batch_device", "rt_render_tiles_batch_device", "rt_render_device_noalloc",
+    "rt_render_batch_device", "rt_render_tiles_batch_device", "rt_render_device_noalloc", "rt_render_batch_host_async", "rt_pinned_alloc", "rt_pinned_free",
     "rt_tiles_owned", "rt_untile_device", "rt_untile_batch_device", "rt_cast_rays", "rt_intersect", "rt_occluded", "rt_trace",
     "rt_intersect_form", "rt_occluded_form", "rt_trace_form", "rt_scene_set_pass_samples",
     "rt_scene_bvh_info", "rt_bvh_check", "rt_scene_bvh_check", "rt_scene_status", "rt_scene_stream", "rt_set_count_work", "rt_get_work", "rt_last_error", "rt_version",
@@ -144,6 +145,11 @@ def load(path=None):
     lib.rt_render_device.argtypes = [vp, C.POINTER(rt_camera), C.POINTER(rt_params), u32, u32, u32, u32,
                                      vp, vp, C.POINTER(rt_stats)]
     lib.rt_render_device_noalloc.argtypes = [vp, C.POINTER(rt_camera), C.POINTER(rt_params), u32, u32, u32, u32, vp, vp]
+    lib.rt_render_batch_host_async.argtypes = [vp, C.POINTER(rt_camera), u32, C.POINTER(rt_params), u32, u32, u32, u32,
+                                               vp, C.c_uint64, vp]
+    lib.rt_pinned_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+    lib.rt_pinned_free.argtypes = [vp]
+    lib.rt_pinned_free.restype = None
     lib.rt_render_tiles_device.argtypes = [vp, C.POINTER(rt_camera), C.POINTER(rt_params), u32, u32, u32,
                                            u32, vp, vp, C.POINTER(rt_stats)]
     lib.rt_render_batch_device.argtypes = [vp, C.POINTER(rt_camera), u32, C.POINTER(rt_params), u32, u32, u32, u32,

@@ -118,6 +118,13 @@ struct rt_scene {
     hipStream_t last_stream = nullptr;   // stream of the most recent asynchronous frame
     uint32_t last_spp = 1;
     uint32_t ws_min_n0 = 0;              // the workspace is sized for at least this many samples per pass (grown after overflows)
+    // rt_render_batch_host_async: two device frame buffers in turn, copied out on a stream of their own, so that the copy of
+    // one call runs under the kernels of the next call on this scene too
+    hipStream_t copy_stream = nullptr;   // created by the first call that needs it
+    uint8_t* d_host_frames[2] = {nullptr, nullptr};
+    size_t host_frames_bytes = 0;
+    hipEvent_t ev_rendered[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
+    uint32_t host_turn = 0;
     void* noalloc_ws = nullptr;          // this device's copy of the file-scope `scratch` array (rt_render_device_noalloc)
     uint32_t pass_samples = 1u << 23;    // level-0 samples per pass (frames with more are cut into passes of whole pixels)
 };
@@ -129,6 +136,9 @@ static int free_scene(rt_scene* s) {
     hipSetDevice(s->device);
     for (void* p : s->owned) hipFree(p);
     hipFree(s->node_a); hipFree(s->node_b); hipFree(s->rays); hipFree(s->hit_n); hipFree(s->hit_p); hipFree(s->queue_e); hipFree(s->queue_s); hipFree(s->d_counters); hipFree(s->d_aa); hipFree(s->d_frame);
+    hipFree(s->d_host_frames[0]); hipFree(s->d_host_frames[1]);
+    for (int k = 0; k < 2; ++k) { if (s->ev_rendered[k]) hipEventDestroy(s->ev_rendered[k]); if (s->ev_copied[k]) hipEventDestroy(s->ev_copied[k]); }
+    if (s->copy_stream) hipStreamDestroy(s->copy_stream);
     if (s->h_counters) hipHostFree(s->h_counters);
     if (s->h_hint) hipHostFree(s->h_hint);
     if (s->h_overflow) hipHostFree(s->h_overflow);
@@ -268,6 +278,7 @@ extern "C" int rt_scene_create_ex(const rt_flat_scene* sc, int device, uint32_t 
     s->packet_auto = true;
     s->d.packet = sc->n_models > 0 ? 1u : 0u;
     if (const char* e = std::getenv("RT_PACKET")) { s->d.packet = sc->n_models > 0 ? uint32_t(std::atoi(e)) : 0u; s->packet_auto = false; }
+    if (flags & RT_SCENE_NO_PACKETS) { s->d.packet = 0; s->packet_auto = false; }
     s->d.user_packet = 0;
     s->pass_samples = default_pass_samples();
     // set-up for rt_render_device_noalloc: the address of the static workspace ON THIS DEVICE (current since hipSetDevice
@@ -329,6 +340,7 @@ extern "C" int rt_scene_status(rt_scene* s) {
     HIP_TRY(hipSetDevice(s->device));
     if (s->last_stream) HIP_TRY(hipStreamSynchronize(s->last_stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->copy_stream) HIP_TRY(hipStreamSynchronize(s->copy_stream));
     const bool over = *s->h_overflow != 0 || s->last_overflow == 1;
     if (*s->h_overflow && s->last_overflow != 1) learn_from_overflow(s, std::max<uint32_t>(64u, RT_PASS_SAMPLES / std::max<uint32_t>(1u, s->last_spp)));   // not yet accounted for
     *s->h_overflow = 0;
@@ -1076,6 +1088,70 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_params* prm
     HIP_TRY(hipStreamSynchronize(s->stream));
     return RT_OK;
 }
+
+// Frames into HOST memory without blocking: rendered into the scene's device frame buffer, copied out by a D2H copy
+// enqueued behind them on the same stream. With page-locked host memory the copy runs at the PCIe rate next to the
+// NEXT call's kernels (another scene, another stream): the pipeline a caller builds from two scenes delivers host
+// frames at nearly the device-framebuffer rate.
+extern "C" int rt_render_batch_host_async(rt_scene* s, const rt_camera* cams, uint32_t n_frames, const rt_params* prm, uint32_t x0,
+                                          uint32_t y0, uint32_t w, uint32_t h, uint8_t* host_bgr, uint64_t frame_stride_bytes,
+                                          void* stream) {
+    if (!s || !host_bgr) { rt_set_error("null argument"); return RT_ERR_INVALID; }
+    int rc = check_batch(cams, n_frames, prm);
+    if (rc != RT_OK) return rc;
+    if ((rc = check_rect(cams, x0, y0, w, h)) != RT_OK) return rc;
+    const size_t frame = size_t(cams->imWidth) * cams->imHeight * 3;
+    if (n_frames > 1 && frame_stride_bytes < frame) { rt_set_error("frame stride smaller than a frame"); return RT_ERR_INVALID; }
+    if (w == 0 || h == 0) return RT_OK;
+    HIP_TRY(hipSetDevice(s->device));
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : s->stream;
+    const size_t need = frame * n_frames;
+    if (!s->copy_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) {
+            HIP_TRY(hipEventCreateWithFlags(&s->ev_rendered[k], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&s->ev_copied[k], hipEventDisableTiming));
+        }
+    }
+    if (need > s->host_frames_bytes) {
+        HIP_TRY(hipStreamSynchronize(s->copy_stream));      // copies out of the old buffers
+        for (int k = 0; k < 2; ++k) {
+            hipFree(s->d_host_frames[k]); s->d_host_frames[k] = nullptr;
+        }
+        s->host_frames_bytes = 0;
+        for (int k = 0; k < 2; ++k) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_host_frames[k]), need));
+        s->host_frames_bytes = need;
+        s->host_turn = 0;
+    }
+    const uint32_t k = s->host_turn++ & 1u;
+    uint8_t* d_frames = s->d_host_frames[k];
+    HIP_TRY(hipStreamWaitEvent(st, s->ev_copied[k], 0));      // the copy that last read this buffer (none yet: no wait)
+    rc = render_frame(s, cams, n_frames, prm, rect_map(cams, x0, y0, w, h), d_frames, frame, st, nullptr, false);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(hipEventRecord(s->ev_rendered[k], st));
+    HIP_TRY(hipStreamWaitEvent(s->copy_stream, s->ev_rendered[k], 0));
+    const size_t pitch = size_t(cams->imWidth) * 3, off = (size_t(y0) * cams->imWidth + x0) * 3;
+    if (w == cams->imWidth && h == cams->imHeight && (n_frames == 1 || frame_stride_bytes == frame)) {
+        HIP_TRY(hipMemcpyAsync(host_bgr, d_frames, need, hipMemcpyDeviceToHost, s->copy_stream));      // whole frames back to back: one copy
+    } else {
+        for (uint32_t b = 0; b < n_frames; ++b) {
+            uint8_t* dst = host_bgr + size_t(frame_stride_bytes) * b + off;
+            const uint8_t* src = d_frames + frame * b + off;
+            if (w == cams->imWidth) HIP_TRY(hipMemcpyAsync(dst, src, pitch * h, hipMemcpyDeviceToHost, s->copy_stream));
+            else HIP_TRY(hipMemcpy2DAsync(dst, pitch, src, pitch, size_t(w) * 3, h, hipMemcpyDeviceToHost, s->copy_stream));
+        }
+    }
+    HIP_TRY(hipEventRecord(s->ev_copied[k], s->copy_stream));
+    return RT_OK;
+}
+
+extern "C" int rt_pinned_alloc(size_t bytes, void** out) {
+    if (!out) { rt_set_error("out is NULL"); return RT_ERR_INVALID; }
+    *out = nullptr;
+    HIP_TRY(hipHostMalloc(out, std::max<size_t>(bytes, 16), hipHostMallocDefault));
+    return RT_OK;
+}
+extern "C" void rt_pinned_free(void* p) { if (p) hipHostFree(p); }
 
 extern "C" uint32_t rt_tiles_owned(uint32_t W, uint32_t H, uint32_t tw, uint32_t th, uint32_t part, uint32_t n_parts) {
     if (!tw || !th || !n_parts || part >= n_parts) return 0;

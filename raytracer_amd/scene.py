@@ -356,13 +356,14 @@ def bvh_check(flat):
 class DeviceScene:
     """rt_scene on one GPU. Fails loudly when the HIP library or a GPU is missing."""
 
-    def __init__(self, flat, device=0, bvh="host"):
-        """bvh = "host": the SAH builder (rt_scene_create); "device": rt_scene_create_ex with RT_SCENE_BVH_DEVICE."""
+    def __init__(self, flat, device=0, bvh="host", packets=True):
+        """bvh = "host": the SAH builder (rt_scene_create); "device": rt_scene_create_ex with RT_SCENE_BVH_DEVICE.
+        packets=False: RT_SCENE_NO_PACKETS (every mesh ray traversed by itself; per-ray work counters)."""
         self.lib = cabi.load()
         self.flat = flat
         self.device = device
         self.h = C.c_void_p()
-        flags = {"host": 0, "device": cabi.RT_SCENE_BVH_DEVICE}[bvh]
+        flags = {"host": 0, "device": cabi.RT_SCENE_BVH_DEVICE}[bvh] | (0 if packets else cabi.RT_SCENE_NO_PACKETS)
         cabi.check(self.lib, self.lib.rt_scene_create_ex(C.byref(flat.c_struct()), device, flags, C.byref(self.h)))
 
     def bvh_check(self):
@@ -421,6 +422,15 @@ class DeviceScene:
         cabi.check(self.lib, self.lib.rt_render_batch_device(self.h, arr, len(cams), C.byref(params.c), x0, y0, w, h,
                                                              C.c_void_p(d_ptr), int(frame_stride), C.c_void_p(stream or 0),
                                                              C.byref(stats) if stats is not None else None))
+
+    def render_batch_host_async(self, cams, params, host_ptr, frame_stride, rect=None, stream=None):
+        """rt_render_batch_host_async: len(cams) frames into host memory (page-locked for a truly asynchronous copy);
+        valid after status()."""
+        arr = (rt_camera * len(cams))(*cams)
+        W, H = cams[0].imWidth, cams[0].imHeight
+        x0, y0, w, h = rect if rect is not None else (0, 0, W, H)
+        cabi.check(self.lib, self.lib.rt_render_batch_host_async(self.h, arr, len(cams), C.byref(params.c), x0, y0, w, h,
+                                                                 C.c_void_p(host_ptr), int(frame_stride), C.c_void_p(stream or 0)))
 
     def render_tiles_batch_device(self, cams, params, tile, part, n_parts, d_ptr, frame_stride, stream=None, stats=None):
         arr = (rt_camera * len(cams))(*cams)

@@ -162,6 +162,20 @@ WORKLOADS = {
 }
 
 
+def orbit_cameras(width, height, n, radius=0.05):
+    """n cameras for the frames of a batch: camera 0 is the reference's (src/raytracer.cpp:674-689), camera k's eye is
+    moved along a small circle through it (radius 0.05 in the x-y plane, 32 positions per turn), so that the frames
+    of a batch are different pictures that share no rays."""
+    import math
+    from .scene import make_camera
+    cams = []
+    for k in range(n):
+        th = 2.0 * math.pi * (k % 32) / 32.0
+        cams.append(make_camera(width, height, fov=60.0,
+                                move=(-0.5 + radius * (math.cos(th) - 1.0), radius * math.sin(th), -0.25)))
+    return cams
+
+
 def make_workload(name):
     factory, W, H, aa, depth = WORKLOADS[name]
     return factory(), reference_camera(W, H), Params(max_depth=depth, aa=aa)

@@ -286,3 +286,43 @@ def test_batch_equals_single_frames():
     got = frames.cpu().numpy()
     for k in range(5):
         assert np.array_equal(got[k], singles[k]), k
+
+
+def test_host_async_batches_equal_device_frames():
+    """rt_render_batch_host_async: frames delivered to host memory (page-locked via rt_pinned_alloc, and pageable) by
+    the scene's copy stream are, byte for byte, the frames of rt_render; several calls in a row reuse the two device
+    frame buffers in turn; a rectangle writes only its bytes."""
+    from raytracer_amd.scene import make_camera
+    fs = wl.scene_bunny(10, third="glass2")
+    dev = DeviceScene(fs)
+    W, H = 328, 200
+    p = Params(max_depth=6)
+    cams = [make_camera(W, H, eye=(0.3 * k, 0.1 * k, 0.2 * k), at=(0.05 * k, 0, -1)) for k in range(6)]
+    singles = [dev.render(c, p)[0] for c in cams]
+    fb = W * H * 3
+    ptr = C.c_void_p()
+    cabi.check(dev.lib, dev.lib.rt_pinned_alloc(6 * fb, C.byref(ptr)))
+    try:
+        host = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(6, H, W, 3))
+        host[:] = 0
+        for first in (0, 2, 4):          # three calls back to back, two frames each, no wait in between
+            dev.render_batch_host_async(cams[first:first + 2], p, ptr.value + first * fb, fb)
+        dev.status()
+        for k in range(6):
+            assert np.array_equal(host[k], singles[k]), k
+        host[:] = 0
+        rect = (40, 16, 200, 120)
+        dev.render_batch_host_async(cams[:3], p, ptr.value, fb, rect=rect)
+        dev.status()
+        x0, y0, w, h = rect
+        for k in range(3):
+            assert np.array_equal(host[k][y0:y0 + h, x0:x0 + w], singles[k][y0:y0 + h, x0:x0 + w]), k
+            host[k][y0:y0 + h, x0:x0 + w] = 0
+        assert not host.any()
+    finally:
+        dev.status()
+        dev.lib.rt_pinned_free(ptr)
+    pageable = np.zeros((2, H, W, 3), np.uint8)
+    dev.render_batch_host_async(cams[1:3], p, pageable.ctypes.data, fb)
+    dev.status()
+    assert np.array_equal(pageable[0], singles[1]) and np.array_equal(pageable[1], singles[2])

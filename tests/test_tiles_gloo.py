@@ -66,3 +66,41 @@ def test_tiles_owned_matches_the_library():
             assert total == tx * ty
     assert lib.rt_tiles_owned(10, 10, 8, 8, 3, 2) == 0       # part >= n_parts
     assert lib.rt_tiles_owned(10, 10, 0, 8, 0, 1) == 0
+
+
+def _run_bench(*argv, env_extra=None):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], env=env, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_gpus_n_starts_n_ranks():
+    """`python bench.py --gpus N` (the driver's form, no launcher) must be N processes: the launcher path, rehearsed
+    without a GPU (--rehearse-launcher: rendezvous over gloo, all-gather of the ranks, rank 0 reports)."""
+    r, d = _run_bench("--gpus", "3", "--rehearse-launcher")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert d["n_gpus"] == 3 and d["rccl_ranks"] == 3 and d["ranks_seen"] == [0, 1, 2] and d["distinct_processes"] == 3
+    # a launcher that disagrees with --gpus is an error, not a silent 1-rank run
+    r, d = _run_bench("--gpus", "4", "--rehearse-launcher", env_extra={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0",
+                                                                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port())})
+    assert r.returncode == 2 and "WORLD_SIZE=2" in r.stderr and d is None
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu():
+    """The whole N-rank script with two ranks sharing GPU 0 (gloo carries the gather: RCCL needs a GPU per rank):
+    tiles dealt to two processes, gathered, untiled; the frames must equal the single-GPU census frames."""
+    r, d = _run_bench("--gpus", "2", "--backend", "gloo", "--single-device", "--steps", "8", "--warmup", "4",
+                      "--workload", "c1_scene_yaml_800x600", "--frames-per-batch", "2")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["frame_identical_to_1gpu"] is True
+    assert d["value"] > 0 and d["config"]["parallelism"].startswith("2 GPUs")

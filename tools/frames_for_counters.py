@@ -1,0 +1,22 @@
+"""Target program of tools/collect_counters.sh: renders, one call per frame on the scene's stream,
+    2 full frames (warm-up: the second knows its level sizes), 1 frame at max_depth 0, 1 full frame.
+A frame starts with one k_set_frame_params launch, so tools/counters_table.py finds frames 3 and 4 by counting those.
+At max_depth 0 a frame runs exactly its level-0 launches, one per kernel: their counters are PER LAUNCH."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from raytracer_amd import workloads as wl  # noqa: E402
+from raytracer_amd.scene import DeviceScene, Params  # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else "bunny_1080p"
+fs, cam, p = wl.make_workload(name)
+p0 = Params(background=tuple(p.c.background), max_depth=0, aa=p.aa)
+dev = DeviceScene(fs)
+frame = torch.zeros((cam.imHeight, cam.imWidth, 3), dtype=torch.uint8, device="cuda")
+torch.cuda.synchronize()
+for prm in (p, p, p0, p):
+    dev.render_device(cam, prm, frame.data_ptr())
+    dev.status()
