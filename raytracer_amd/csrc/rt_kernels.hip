@@ -1369,12 +1369,44 @@ __global__ __launch_bounds__(256) void k_fold(DScene S, LevelArgs A) {
 }
 
 // render(): px += trace(...) / numRays per sample, then (uchar)(c*255) as B,G,R (reference src/raytracer.cpp:436-448).
-// One thread per pixel of the pass; level-0 nodes of a pixel are consecutive.
+// One thread per pixel of the pass; the level-0 nodes of a pixel are consecutive (spp of them, 32 B each in node_a /
+// node_b). The sum over a pixel's samples is a chain of float additions in sample order, so it stays with one lane;
+// the loads do not: a lane that walks its own pixel's samples touches a different cache line than its neighbours in
+// every load (64 lines per wave-instruction, of which 16 B each are used, evicted from the 32-KB L1 before the lane
+// comes back for the next 16 B: measured 8.5x the algorithmic bytes from HBM at 16 spp, a tenth of the 4K and 8K
+// frames' time). So the wave reads its 64 pixels' samples 8 at a time with lane l on pixel l / 8, sample l % 8 of
+// the chunk - every 8 lanes read one whole 128-B line of each array - and the colours change hands through LDS
+// ([sample of the chunk][pixel], rows 72 words apart: conflict-free both ways).
+#define RT_RESOLVE_CHUNK 8u
 __global__ __launch_bounds__(256) void k_resolve(DScene S, LevelArgs A, uint8_t* __restrict__ out) {
+    __shared__ float lds[4][3][RT_RESOLVE_CHUNK][72];
     const uint32_t npix = A.n0 / A.spp;
     const uint32_t p = blockIdx.x * 256 + threadIdx.x;
     if (p == 0 && A.host_overflow && *A.overflow)       // tell the host without a copy: the pass ran out of pool
         __hip_atomic_store(A.host_overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const float inv = 1 / (float)A.spp;        // color.h:27-30
+    V3 px = mk(0, 0, 0);
+    if (A.spp == 1) {
+        if (p < npix) px = node_color(S, A.node_a, A.node_b, p) * inv;
+    } else {
+        const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+        const uint32_t p0 = p - lane;                       // the wave's first pixel (npix is a multiple of 64)
+        float (*w)[RT_RESOLVE_CHUNK][72] = lds[wave];
+        for (uint32_t s0 = 0; s0 < A.spp; s0 += RT_RESOLVE_CHUNK) {      // uniform over the workgroup
+            const uint32_t chunk = A.spp - s0 < RT_RESOLVE_CHUNK ? A.spp - s0 : RT_RESOLVE_CHUNK;
+            const uint32_t k = lane & 7u;
+#pragma unroll
+            for (uint32_t j = 0; j < 8; ++j) {
+                const uint32_t q = j * 8u + (lane >> 3);    // pixel of the wave
+                V3 c = mk(0, 0, 0);
+                if (k < chunk && p0 + q < npix) c = node_color(S, A.node_a, A.node_b, (p0 + q) * A.spp + s0 + k) * inv;
+                w[0][k][q] = c.x; w[1][k][q] = c.y; w[2][k][q] = c.z;
+            }
+            __syncthreads();
+            for (uint32_t kk = 0; kk < chunk; ++kk) px = px + mk(w[0][kk][lane], w[1][kk][lane], w[2][kk][lane]);
+            __syncthreads();
+        }
+    }
     if (p >= npix) return;
     uint32_t x, y; uint64_t off; bool inb;
     uint64_t q = A.sample0 / A.spp + p;
@@ -1388,12 +1420,6 @@ __global__ __launch_bounds__(256) void k_resolve(DScene S, LevelArgs A, uint8_t*
     if (!valid) {
         if (A.pm.tiled_out && inb) { out[off] = 0; out[off + 1] = 0; out[off + 2] = 0; }
         return;
-    }
-    const float inv = 1 / (float)A.spp;        // color.h:27-30
-    V3 px = mk(0, 0, 0);
-    for (uint32_t s = 0; s < A.spp; ++s) {
-        const V3 c = node_color(S, A.node_a, A.node_b, p * A.spp + s);
-        px = px + c * inv;
     }
     out[off] = (uint8_t)(px.z * 255);
     out[off + 1] = (uint8_t)(px.y * 255);

@@ -147,6 +147,8 @@ WORKLOADS = {
     # BASELINE config 2
     "c2_analytic_1080p_4spp": (lambda: scene_analytic(shadows_only=True), 1920, 1080,
                                ((0.5, 0.5), (0.25, 0.75), (0.75, 0.25)), 10),
+    # the analytic part of scene.yaml alone at the bench's size (diagnostics: what the frame costs without its mesh)
+    "analytic_1080p": (lambda: scene_analytic(), 1920, 1080, (), 10),
     # BASELINE config 3 (strict reading: Phong + hard shadows only)
     "c3_bunny_1080p_shadows": (lambda: scene_bunny(59, shadows_only=True, spheres=False), 1920, 1080, (), 10),
     # The metric's "bunny scene 1920x1080" with the scene file's own materials (reflections + shadows): bench default

@@ -21,3 +21,6 @@ rm -rf gpurun_out/ctr_trace
 timeout -k 10 $LIM rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ctr_trace -o p -- python3 tools/frames_for_counters.py $W > gpurun_out/ctr_trace.log 2>&1 \
   || { echo "trace pass failed"; tail -5 gpurun_out/ctr_trace.log; exit 1; }
 python3 tools/counters_table.py $W
+# the raw CSVs of a large frame are hundreds of MB (gpurun_out/ is copied back only up to 64 MiB): keep the table's JSON
+rm -rf gpurun_out/ctr_sq1 gpurun_out/ctr_sq2 gpurun_out/ctr_fetch gpurun_out/ctr_write gpurun_out/ctr_tcc
+mkdir -p gpurun_out/trace_$W && cp gpurun_out/ctr_trace/*kernel_stats.csv gpurun_out/trace_$W/ 2>/dev/null; rm -rf gpurun_out/ctr_trace
