@@ -614,7 +614,8 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
         const int levels = s->has_bounce ? A.max_depth : 0;
         const bool overlap = !J.timed;
         hipStream_t sa = J.st;
-        const uint32_t grid0 = (A.n0 + RT_BLOCK - 1) / RT_BLOCK;
+        uint32_t grid0 = (A.n0 + RT_BLOCK - 1) / RT_BLOCK;
+        if (const char* e = std::getenv("RT_GRID0")) grid0 = std::min<uint32_t>(grid0, uint32_t(std::max(1, std::atoi(e))));      // experiments
         const uint32_t grid0q = std::min<uint32_t>((A.n0 + 15) / 16, 4u * RT_LEVEL_GRID);
         int rc;
         bool used_shade[3] = {false, false, false};
@@ -628,8 +629,9 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
         // diagnostics: RT_WAVE_LOG=<level>:<file> dumps per-workgroup timing of that level's quad extend kernel (COUNT builds)
         uint4* wave_log = nullptr;
         int log_level = -1;
+        const bool log_shade = std::getenv("RT_WAVE_LOG_SHADE") != nullptr;      // the level's per-lane shade kernel instead of its extend kernel
         const char* log_path = nullptr;
-        if (s->count_work) {
+        {
             if (const char* e = std::getenv("RT_WAVE_LOG")) {
                 log_level = std::atoi(e);
                 log_path = std::strchr(e, ':');
@@ -652,6 +654,7 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
                 LevelArgs B = A;
                 B.level = part == 0 ? 0 : (lo == 0 && hi > 0 ? 1 : lo);
                 B.level_hi = part == 0 ? 0 : hi;
+                B.wave_log = (log_shade && B.level == log_level) ? wave_log : nullptr;
                 const bool wide = form == RT_FORM_WIDE || form == RT_FORM_WIDE_SERVE;
                 const uint32_t wide_grid = (small_run && wide) ? wide_grid_for(s, slot, B.level, B.level_hi) : RT_LEVEL_GRID;
                 const uint32_t g = wide ? (B.level_hi == 0 ? grid0 : wide_grid)
@@ -689,6 +692,7 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
             B.level = lv; B.level_hi = lv;
             const int src = lv == 0 ? 0 : 1;
             const bool large = !meshes || lv == 0 || expect_large(s, slot, lv, lv);
+            B.wave_log = (lv == log_level && !log_shade) ? wave_log : nullptr;
             if (large) {
                 if (small_lo >= 0) {     // shade the small levels before this one
                     if (overlap) HIP_TRY(record(2 * lv));
@@ -700,7 +704,6 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
                 // level 0 of a packet scene: the per-lane kernels traverse the meshes themselves, nothing is suspended
                 const bool quads = meshes && !((lv == 0 && s->d.packet) || s->d.packet >= 2);
                 if (quads) {
-                    B.wave_log = (lv == log_level) ? wave_log : nullptr;
                     if ((rc = timed_launch(J, sa, RT_K_EXTEND_QUAD, [&] { launch_extend(src, RT_FORM_QUAD_RESUME, s->count_work, s->d, B, lv == 0 ? grid0q : 4u * RT_LEVEL_GRID, sa); })) != RT_OK) return rc;
                     if (overlap) HIP_TRY(record(2 * lv + 1));
                 }
@@ -711,7 +714,6 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
                     if ((rc = shade(RT_FORM_QUAD_PARKED, lv, lv, 2 * lv + 1)) != RT_OK) return rc;
                 }
             } else {
-                B.wave_log = (lv == log_level) ? wave_log : nullptr;
                 // (the same split for the extend side - per-lane kernel, queue, resuming quads, launches sized by the hints -
                 // was measured slower at every level size: bunny_1080p 0.325 -> 0.345 ms, 10 M-triangle field 5.40 -> 5.67..5.86:
                 // most bounce rays reach the mesh anyway, and their state makes a round trip through memory)

@@ -30,6 +30,11 @@
 #include "rt_launch.h"
 
 #define RT_EPS 0.000001f   // reference src/common.h:36
+#define RT_WIDE_BLOCK_MAX 256
+#ifndef RT_WIDE_BLOCK_DEFAULT
+#define RT_WIDE_BLOCK_DEFAULT 64
+#endif
+#include <cstdlib>
 
 struct V3 { float x, y, z; };
 __device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
@@ -1006,11 +1011,15 @@ __device__ __forceinline__ void extend_wide_body(const DScene& S, const LevelArg
     const uint32_t next_base_l = v.start + v.cnt;     // lane s: children of shard s are appended behind its level
     Work wk = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (COUNT) { wk.t_start = wall_clock64(); wk.c_start = clock64(); }
+    else if (A.wave_log) wk.t_start = wall_clock64();      // diagnostics (RT_WAVE_LOG): the wave's start and end, nothing else
 
-    for (uint32_t grp = blockIdx.x; grp < G.total; grp += gridDim.x) {
+    // a workgroup is 1..4 independent waves (RT_WIDE_BLOCK: the dispatcher starts workgroups at a limited rate, and these
+    // waves are short-lived), wave w of workgroup b takes groups b * waves + w, ...
+    const uint32_t nwv = blockDim.x >> 6;
+    for (uint32_t grp = blockIdx.x * nwv + (threadIdx.x >> 6); grp < G.total; grp += gridDim.x * nwv) {
         uint32_t shard, pos, lim;
         locate(G, grp, shard, pos, lim);
-        const uint32_t i = pos + threadIdx.x;
+        const uint32_t i = pos + (threadIdx.x & 63u);
         const bool active = i < lim;
         Ray ray;
         ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 0);
@@ -1031,10 +1040,19 @@ __device__ __forceinline__ void extend_wide_body(const DScene& S, const LevelArg
         extend_finish(S, A, i, active && !parked, valid && !parked, true, ray, h, lane_read(next_base_l, shard),
                       A.n0 + (shard + 1u) * A.sub_cap, sc->level + (A.level + 1), 0u);
     }
-    if (COUNT) flush_work(A.work, PACKET == 2 ? 2 : 0, wk);
+    if (COUNT) {
+        const uint32_t steps = wave_sum(wk.wave_nodes + wk.wave_tris);
+        const uint32_t wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        if (A.wave_log && lane_id() == 0 && wid < 4u * 8192u)
+            A.wave_log[wid] = make_uint4((uint32_t)wk.t_start, (uint32_t)wall_clock64(), steps, (uint32_t)(clock64() - wk.c_start));
+        flush_work(A.work, PACKET == 2 ? 2 : 0, wk);
+    } else if (A.wave_log && lane_id() == 0) {
+        const uint32_t wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        if (wid < 4u * 8192u) A.wave_log[wid] = make_uint4((uint32_t)wk.t_start, (uint32_t)wall_clock64(), 0u, 0u);
+    }
 }
 template <int SRC, bool COUNT, bool PACKET>
-__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(PACKET ? RT_WPE_PK : RT_WPE_EW))) void k_extend_wide(DScene S, LevelArgs A) {
+__global__ __launch_bounds__(RT_WIDE_BLOCK_MAX) __attribute__((amdgpu_waves_per_eu(PACKET ? RT_WPE_PK : RT_WPE_EW))) void k_extend_wide(DScene S, LevelArgs A) {
     extend_wide_body<SRC, COUNT, PACKET ? 1 : 0>(S, A, nullptr);
 }
 // the rays of a level >= 1, one per lane, meshes by quad service
@@ -1199,11 +1217,13 @@ __device__ __forceinline__ void shade_wide_body(const DScene& S, const LevelArgs
     const Groups G = level0 ? make_groups_dense<false>(A.n0, A.chunk_log2) : make_groups<false>(v.start, v.cnt);
     Work wk = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (COUNT) { wk.t_start = wall_clock64(); wk.c_start = clock64(); }
+    else if (A.wave_log) wk.t_start = wall_clock64();
     uint32_t n_shadow = 0;
-    for (uint32_t grp = blockIdx.x; grp < G.total; grp += gridDim.x) {
+    const uint32_t nwv = blockDim.x >> 6;      // see extend_wide_body
+    for (uint32_t grp = blockIdx.x * nwv + (threadIdx.x >> 6); grp < G.total; grp += gridDim.x * nwv) {
         uint32_t shard, pos, lim;
         locate(G, grp, shard, pos, lim);
-        const uint32_t i = pos + threadIdx.x;
+        const uint32_t i = pos + (threadIdx.x & 63u);
         uint4 b = make_uint4(0, 0, 0, 0);
         if (i < lim) b = A.node_b[i];
         const bool hit = (b.w & (NODE_HIT | NODE_PARKED)) == NODE_HIT;
@@ -1221,10 +1241,19 @@ __device__ __forceinline__ void shade_wide_body(const DScene& S, const LevelArgs
         }
     }
     flush_shadow(A, n_shadow);
-    if (COUNT) flush_work(A.work, PACKET == 2 ? 3 : 1, wk);
+    if (COUNT) {
+        const uint32_t steps = wave_sum(wk.wave_nodes + wk.wave_tris);
+        const uint32_t wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        if (A.wave_log && lane_id() == 0 && wid < 4u * 8192u)
+            A.wave_log[wid] = make_uint4((uint32_t)wk.t_start, (uint32_t)wall_clock64(), steps, (uint32_t)(clock64() - wk.c_start));
+        flush_work(A.work, PACKET == 2 ? 3 : 1, wk);
+    } else if (A.wave_log && lane_id() == 0) {
+        const uint32_t wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        if (wid < 4u * 8192u) A.wave_log[wid] = make_uint4((uint32_t)wk.t_start, (uint32_t)wall_clock64(), 0u, 0u);
+    }
 }
 template <bool COUNT, bool GPOW, bool PACKET>
-__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(PACKET ? RT_WPE_PK : RT_WPE_SW))) void k_shade_wide(DScene S, LevelArgs A) {
+__global__ __launch_bounds__(RT_WIDE_BLOCK_MAX) __attribute__((amdgpu_waves_per_eu(PACKET ? RT_WPE_PK : RT_WPE_SW))) void k_shade_wide(DScene S, LevelArgs A) {
     shade_wide_body<COUNT, GPOW, PACKET ? 1 : 0>(S, A, nullptr);
 }
 // the hits of levels >= 1, one per lane, shadow rays through meshes by quad service
@@ -1637,10 +1666,17 @@ hipError_t noalloc_scratch(int device, void** ptr) {
 // ---------------------------------------------------------------------------------------------------------
 extern "C++" {
 
+// Waves per workgroup of the per-lane kernels (RT_WIDE_BLOCK in the environment: threads, for experiments).
+static uint32_t wide_waves() {
+    static const uint32_t n = [] { const char* e = std::getenv("RT_WIDE_BLOCK"); const int t = e ? std::atoi(e) : RT_WIDE_BLOCK_DEFAULT; return (uint32_t)std::max(1, std::min(RT_WIDE_BLOCK_MAX, t) / 64); }();
+    return n;
+}
 template <int SRC>
 static void launch_extend_src(int form, bool count, const DScene& S, const LevelArgs& A, dim3 g, hipStream_t st) {
     dim3 b(RT_BLOCK);
     if (form == RT_FORM_WIDE) {
+        b = dim3(64u * wide_waves());
+        g = dim3((g.x + wide_waves() - 1u) / wide_waves());
         if ((SRC == 0 && S.packet) || (SRC == 1 && S.packet >= 2) || (SRC == 2 && S.user_packet)) {     // primary rays: coherent, traversed as packets in the per-lane kernel itself (2: deeper levels too; user_packet: rt_trace_form)
             if (count) hipLaunchKernelGGL((k_extend_wide<SRC, true, true>), g, b, 0, st, S, A);
             else hipLaunchKernelGGL((k_extend_wide<SRC, false, true>), g, b, 0, st, S, A);
@@ -1669,6 +1705,8 @@ void launch_extend(int src, int form, bool count, const DScene& S, const LevelAr
 template <bool COUNT, bool GPOW>
 static void launch_shade_t(int form, const DScene& S, const LevelArgs& A, dim3 g, dim3 b, hipStream_t st) {
     if (form == RT_FORM_WIDE) {
+        b = dim3(64u * wide_waves());
+        g = dim3((g.x + wide_waves() - 1u) / wide_waves());
         // the hits of primary rays: their shadow rays are coherent too (rt_trace's caller-supplied rays need not be)
         if (S.packet && (A.level == 0 || S.packet >= 2) && (!A.user_rays || S.user_packet)) hipLaunchKernelGGL((k_shade_wide<COUNT, GPOW, true>), g, b, 0, st, S, A);
         else hipLaunchKernelGGL((k_shade_wide<COUNT, GPOW, false>), g, b, 0, st, S, A);
