@@ -524,6 +524,9 @@ def extras(args, out, dev, slots, fs, cam, cams, params, st, rays_per_frame, cam
     if ctr_files:
         cj = json.load(open(ctr_files[-1]))
         ctr = cj.get("depth0", {}).get(rocprof_names[dk])
+        if ctr:      # a frame of several passes launches the kernel once per pass: counters per LAUNCH
+            nl = max(ctr.get("launches", 1.0), 1.0)
+            ctr = {k: v / nl for k, v in ctr.items()}
         ctr_src = {"file": os.path.relpath(ctr_files[-1], ROOT), "commit": cj.get("commit"), "kernel": rocprof_names[dk],
                    "note": "counters come from this committed file, durations and work counts are measured live"}
     roof = {"kernel": rocprof_names[dk], "avg_launch_ms": avg_ms, "launches_per_frame_at_depth0": n0[dk] / reps,
