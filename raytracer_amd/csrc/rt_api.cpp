@@ -47,7 +47,7 @@ struct PassCounters {                 // one per pass, zeroed by one memset per 
     ShardCounters sc[RT_SHARDS];         // per shard: entries appended / queued per level
     uint32_t cancel[RT_MAX_LEVELS + 4];  // per level: children of parents that took trace()'s `return red` exit
     uint32_t overflow;
-    uint32_t pad[3];
+    uint32_t tail_bar[3];                // k_tail: arrivals of its two roles, abort flag
     unsigned long long shadow[RT_STAT_SHARDS];
     unsigned long long work[RT_WORK_SHARDS][RT_N_KINDS][12];   // per shard: RT_K_* kernels
     uint32_t appended(int lv) const { uint32_t n = 0; for (uint32_t k = 0; k < RT_SHARDS; ++k) n += sc[k].level[lv]; return n; }
@@ -682,12 +682,59 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
             // have nothing in common - 10 M-triangle field at 8K 64 spp 717 -> 970 ms)
             if (serve && level_hint(s, slot, lo) < 0xFFFFFFFFull) return shade(RT_FORM_WIDE_SERVE, lo, hi, after, true);
             if (!split_small || s->d.packet >= 2) return shade(RT_FORM_QUAD_FRESH, lo, hi, after);
+            // a run of a few hundred hits: two launches would cost more than the instructions one quad launch repeats
+            {
+                static const int tiny_default = 1024;
+                const char* e = std::getenv("RT_TINY_RUN");
+                uint64_t n = 0;
+                for (int l = lo; l <= hi; ++l) n += level_hint(s, slot, l);
+                if (n <= uint64_t(e ? std::max(0, std::atoi(e)) : tiny_default)) return shade(RT_FORM_QUAD_FRESH, lo, hi, after);
+            }
             const int rc2 = shade(RT_FORM_WIDE, lo, hi, after, true);
             if (rc2 != RT_OK) return rc2;
             return shade(RT_FORM_QUAD_RESUME, lo, hi, after, true);
         };
         int small_lo = -1;      // first level of the run of small levels not shaded yet
+        // The tail (opt-in, RT_TAIL=<rays>): from the first level on behind which every level is expected to hold at most
+        // that many rays, closest hits, light loops and folds of all those levels are ONE launch (k_tail) on the caller's
+        // stream instead of two to three dependent launches per level. Same bytes; measured SLOWER on MI355X (bunny_1080p
+        // one frame at a time 0.71 -> 0.75 ms with levels 3..10 in the tail, batched 0.296 -> 0.337): a level costs the
+        // latency of its longest ray (12-35 us) either way, and a grid barrier across the 8 XCDs (L2 write-back, agent-
+        // scope atomic and poll, invalidate: 6-9 us, then cold caches) is no cheaper than a launch boundary (~5 us).
+        int lv_tail = levels + 1;
+        uint32_t tail_wg = RT_TAIL_MAX_WG;
+        {
+            static const int tail_default = 0;
+            const char* e = std::getenv("RT_TAIL");      // experiments and tests: rays per level, 0 = never
+            const uint64_t thr = uint64_t(e ? std::max(0, std::atoi(e)) : tail_default);
+            if (const char* w = std::getenv("RT_TAIL_WG")) tail_wg = std::min<uint32_t>(RT_TAIL_MAX_WG, std::max(2, std::atoi(w))) & ~1u;
+            if (meshes && thr && !s->count_work && !wave_log)
+                while (lv_tail > 1 && level_hint(s, slot, lv_tail - 1) <= thr) --lv_tail;
+        }
         for (int lv = 0; lv <= levels; ++lv) {
+            if (lv == lv_tail) {
+                if (small_lo >= 0) {     // shade the small levels before the tail
+                    if (overlap) HIP_TRY(record(2 * lv));
+                    if ((rc = shade_small(small_lo, lv - 1, 2 * lv)) != RT_OK) return rc;
+                    small_lo = -1;
+                }
+                LevelArgs T = A;
+                uint4* tail_log = nullptr;
+                const char* tl = std::getenv("RT_TAIL_LOG");      // diagnostics: per-phase times of two E workgroups -> file
+                if (tl && hipMalloc(reinterpret_cast<void**>(&tail_log), sizeof(uint4) * 128) == hipSuccess) {
+                    hipMemsetAsync(tail_log, 0, sizeof(uint4) * 128, sa);
+                    T.wave_log = tail_log;
+                }
+                if ((rc = timed_launch(J, sa, RT_K_EXTEND_QUAD, [&] { launch_tail(s->d, T, lv_tail, levels, pc->tail_bar, tail_wg, sa); })) != RT_OK) return rc;
+                if (tail_log) {
+                    uint4 h[128];
+                    hipStreamSynchronize(sa);
+                    hipMemcpy(h, tail_log, sizeof h, hipMemcpyDeviceToHost);
+                    if (FILE* f = std::fopen(tl, "wb")) { std::fwrite(h, sizeof(uint4), 128, f); std::fclose(f); }
+                    hipFree(tail_log);
+                }
+                break;
+            }
             LevelArgs B = A;
             B.level = lv; B.level_hi = lv;
             const int src = lv == 0 ? 0 : 1;
@@ -749,7 +796,10 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
             }
         // (folding the deep levels, which hold few nodes, by ONE workgroup in one launch was measured again with the sharded
         // pool: 85 us against 9 launches x 5 us, 0.706 vs 0.686 ms/frame)
-        const int fold_hi = levels - 1;
+        const int fold_hi = std::min(levels, lv_tail) - 1;      // (the tail folds its own levels)
+        // (the deep levels, a few hundred nodes each, folded by ONE 16-wave workgroup with a workgroup barrier per level:
+        // measured no different, 0.685 against 0.676 ms one frame at a time - a level's fold is ~5 us of dependent loads
+        // - counters, node, children - whether it is a launch of its own or not; all levels that way: 85 us against 9 x 5)
         for (int lv = fold_hi; lv >= 1; --lv) {
             A.level = lv; A.level_hi = lv;
             launch_fold(s->d, A, 1024, sa);

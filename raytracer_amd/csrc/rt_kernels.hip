@@ -929,8 +929,8 @@ __device__ __forceinline__ HitState fresh_hit() {
 
 // Rays per wave of a quad kernel: 16, or fewer when the items would not fill the chip's wave slots anyway (a wave
 // lasts as long as its longest ray; with everything resident at once, thinner waves end sooner).
-__device__ __forceinline__ uint32_t quads_per_wave(uint32_t n_items) {
-    const uint32_t slots = gridDim.x < 4096u ? gridDim.x : 4096u;
+__device__ __forceinline__ uint32_t quads_per_wave(uint32_t n_items, uint32_t vgrid) {
+    const uint32_t slots = vgrid < 4096u ? vgrid : 4096u;
     const uint32_t per = (n_items + slots - 1) / slots;
     return per < 1u ? 1u : (per < 16u ? per : 16u);
 }
@@ -945,12 +945,12 @@ struct Groups {
     bool blocks;                 // level 0, marked entries: group g = the whole 64-entry block g (its runs of R one after the other)
 };
 template <bool QUAD>
-__device__ __forceinline__ Groups make_groups(uint32_t first, uint32_t cnt) {
+__device__ __forceinline__ Groups make_groups(uint32_t first, uint32_t cnt, uint32_t vgrid = gridDim.x) {
     Groups G;
     const uint32_t lane = lane_id();
     if (lane >= RT_SHARDS) cnt = 0;
     G.first = first; G.cnt = cnt; G.n_dense = 0; G.chunk_log2 = 0; G.blocks = false;
-    G.R = QUAD ? quads_per_wave(wave_sum(cnt)) : (uint32_t)RT_BLOCK;
+    G.R = QUAD ? quads_per_wave(wave_sum(cnt), vgrid) : (uint32_t)RT_BLOCK;
     uint32_t v = (cnt + G.R - 1) / G.R;
     for (uint32_t off = 1; off < RT_SHARDS; off <<= 1) {
         const uint32_t t = __shfl_up(v, off);
@@ -961,13 +961,13 @@ __device__ __forceinline__ Groups make_groups(uint32_t first, uint32_t cnt) {
     return G;
 }
 template <bool QUAD>
-__device__ __forceinline__ Groups make_groups_dense(uint32_t n, uint32_t chunk_log2) {
+__device__ __forceinline__ Groups make_groups_dense(uint32_t n, uint32_t chunk_log2, uint32_t vgrid = gridDim.x) {
     Groups G;
     G.chunk_log2 = chunk_log2;
     G.first = G.cnt = G.gend = 0;
     G.n_dense = n;
     uint32_t R = RT_BLOCK;
-    if (QUAD) { R = quads_per_wave(n); R = 1u << (31 - __clz((int)R)); }     // a group must not straddle two shards
+    if (QUAD) { R = quads_per_wave(n, vgrid); R = 1u << (31 - __clz((int)R)); }     // a group must not straddle two shards
     G.R = R;
     G.total = (n + R - 1) / R;
     G.blocks = false;
@@ -976,8 +976,8 @@ __device__ __forceinline__ Groups make_groups_dense(uint32_t n, uint32_t chunk_l
 // Level 0, marked entries (pick_marked). With enough blocks to keep the chip busy a wave takes a whole block and works
 // its runs off one after the other: an empty block costs one look instead of 64/R, a full one loads its marks once.
 template <bool QUAD>
-__device__ __forceinline__ Groups make_groups_marked(uint32_t n, uint32_t chunk_log2) {
-    Groups G = make_groups_dense<QUAD>(n, chunk_log2);
+__device__ __forceinline__ Groups make_groups_marked(uint32_t n, uint32_t chunk_log2, uint32_t vgrid = gridDim.x) {
+    Groups G = make_groups_dense<QUAD>(n, chunk_log2, vgrid);
     const uint32_t n_blocks = (n + 63u) >> 6;
     if (n_blocks >= 65536u) { G.blocks = true; G.R = 16; G.total = n_blocks; }     // (at 32 k blocks, one 1080p frame, the serial runs cost more than the looks: 0.11 -> 0.21 ms)
     return G;
@@ -1065,23 +1065,27 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WPE
 
 // k_extend_quad: one ray per quad. FRESH: all rays of the level from the start (levels with few rays: no per-lane
 // kernel runs for them). !FRESH: the rays k_extend_wide queued, resumed at the mesh they stopped at.
+// The body works for "virtual" workgroup vblock of vgrid single-wave workgroups (the kernel: blockIdx.x of gridDim.x; the
+// tail kernel k_tail: one of the waves of its role) with `lds_stack` = this wave's 16-column traversal stack. `direct`:
+// group = virtual block (k_tail) instead of the CU-aware mapping of group_of.
 template <int SRC, bool FRESH, bool COUNT>
-__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WPE_EQ))) void k_extend_quad(DScene S, LevelArgs A) {
-    __shared__ uint32_t lds_stack[RT_QSTACK * 16];
-    const uint32_t quad = threadIdx.x >> 2, j = threadIdx.x & 3u;
+__device__ __forceinline__ void extend_quad_body(const DScene& S, const LevelArgs& A, uint32_t* lds_stack, uint32_t vblock, uint32_t vgrid, bool direct) {
+    const uint32_t quad = (threadIdx.x & 63u) >> 2, j = threadIdx.x & 3u;
     uint32_t* qs = lds_stack + quad;
+    // (s_setprio(3) for these waves - the frame's chain of dependent launches, which shares the SIMDs with the light loops
+    // of the levels above - measured no different: 0.684 / 0.689 against 0.679 / 0.688 ms one frame at a time)
 
     const bool level0 = SRC != 1;
     const ShardView v = shard_view(A, A.level, A.level);
     const uint32_t next_base_l = v.start + v.cnt;
     Groups G;
     if (FRESH) {
-        G = level0 ? make_groups_dense<true>(A.n0, A.chunk_log2) : make_groups<true>(v.start, v.cnt);
+        G = level0 ? make_groups_dense<true>(A.n0, A.chunk_log2, vgrid) : make_groups<true>(v.start, v.cnt, vgrid);
     } else if (level0) {      // the marked entries, block by block
-        G = make_groups_marked<true>(A.n0, A.chunk_log2);
+        G = make_groups_marked<true>(A.n0, A.chunk_log2, vgrid);
     } else {                  // the shard's queue
         const uint32_t q = A.sc[lane_id() & (RT_SHARDS - 1u)].qe[A.level];
-        G = make_groups<true>(v.start, q < v.cnt ? q : v.cnt);
+        G = make_groups<true>(v.start, q < v.cnt ? q : v.cnt, vgrid);
     }
     Work wk = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (COUNT) { wk.t_start = wall_clock64(); wk.c_start = clock64(); }
@@ -1091,8 +1095,8 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WPE
     const uint32_t run_log2 = (A.debug >> 8) ? ((A.debug >> 8) & 31u) : RT_RUN_LOG2;
     const uint32_t rl = run_log2 >= 31u ? 0u : run_log2;
     const uint32_t per_cu = ((((G.total + 255u) >> 8) + (1u << rl) - 1u) >> rl) << rl;
-    for (uint32_t vb = blockIdx.x; vb < per_cu * 256u; vb += gridDim.x) {
-        const uint32_t grp = group_of(vb, per_cu, run_log2);
+    for (uint32_t vb = vblock; vb < (direct ? G.total : per_cu * 256u); vb += vgrid) {
+        const uint32_t grp = direct ? vb : group_of(vb, per_cu, run_log2);
         if (grp >= G.total) continue;
         uint32_t shard, pos0, lim;
         locate(G, grp, shard, pos0, lim);
@@ -1135,7 +1139,12 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WPE
     }
     if (COUNT) flush_work(A.work, 2, wk);
     if (COUNT && A.wave_log && lane_id() == 0)
-        A.wave_log[blockIdx.x] = make_uint4((uint32_t)wk.t_start, (uint32_t)wall_clock64(), (uint32_t)wk.trav_ticks, (uint32_t)(clock64() - wk.c_start));
+        A.wave_log[vblock] = make_uint4((uint32_t)wk.t_start, (uint32_t)wall_clock64(), (uint32_t)wk.trav_ticks, (uint32_t)(clock64() - wk.c_start));
+}
+template <int SRC, bool FRESH, bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WPE_EQ))) void k_extend_quad(DScene S, LevelArgs A) {
+    __shared__ uint32_t lds_stack[RT_QSTACK * 16];
+    extend_quad_body<SRC, FRESH, COUNT>(S, A, lds_stack, blockIdx.x, gridDim.x, false);
 }
 
 // Light loop of trace() (reference src/raytracer.cpp:311-345) for one hit, starting at light li0 / object k0 of its
@@ -1268,23 +1277,22 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WPE
 //   MODE 1  the hits k_shade_wide queued (queue_s of A.level), resumed where they stopped
 //   MODE 2  the hits of the rays that went through the extend queue (queue_e of A.level), from the start
 template <int MODE, bool COUNT, bool GPOW>
-__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WPE_SQ))) void k_shade_quad(DScene S, LevelArgs A) {
+__device__ __forceinline__ void shade_quad_body(const DScene& S, const LevelArgs& A, uint32_t* lds_stack, uint32_t vblock, uint32_t vgrid, bool direct) {
     constexpr bool FRESH = MODE != 1;
-    __shared__ uint32_t lds_stack[RT_QSTACK * 16];
-    const uint32_t quad = threadIdx.x >> 2, j = threadIdx.x & 3u;
+    const uint32_t quad = (threadIdx.x & 63u) >> 2, j = threadIdx.x & 3u;
     uint32_t* qs = lds_stack + quad;
 
     const bool level0 = A.level == 0;                 // then level_hi == 0
     const ShardView v = shard_view(A, A.level, A.level_hi);
     Groups G;
     if (MODE != 0 && level0) {      // MODE 1, 2 at level 0: the marked entries, block by block
-        G = make_groups_marked<true>(A.n0, A.chunk_log2);
+        G = make_groups_marked<true>(A.n0, A.chunk_log2, vgrid);
     } else if (MODE == 0) {
-        G = level0 ? make_groups_dense<true>(A.n0, A.chunk_log2) : make_groups<true>(v.start, v.cnt);
+        G = level0 ? make_groups_dense<true>(A.n0, A.chunk_log2, vgrid) : make_groups<true>(v.start, v.cnt, vgrid);
     } else {
         const ShardCounters* c = A.sc + (lane_id() & (RT_SHARDS - 1u));
         const uint32_t q = MODE == 1 ? c->qs[A.level] : c->qe[A.level];
-        G = make_groups<true>(v.start, q < v.cnt ? q : v.cnt);
+        G = make_groups<true>(v.start, q < v.cnt ? q : v.cnt, vgrid);
     }
     Work wk = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (COUNT) { wk.t_start = wall_clock64(); wk.c_start = clock64(); }
@@ -1294,8 +1302,8 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WPE
     const uint32_t run_log2 = (A.debug >> 8) ? ((A.debug >> 8) & 31u) : RT_RUN_LOG2;
     const uint32_t rl = run_log2 >= 31u ? 0u : run_log2;
     const uint32_t per_cu = ((((G.total + 255u) >> 8) + (1u << rl) - 1u) >> rl) << rl;
-    for (uint32_t vb = blockIdx.x; vb < per_cu * 256u; vb += gridDim.x) {
-        const uint32_t grp = group_of(vb, per_cu, run_log2);
+    for (uint32_t vb = vblock; vb < (direct ? G.total : per_cu * 256u); vb += vgrid) {
+        const uint32_t grp = direct ? vb : group_of(vb, per_cu, run_log2);
         if (grp >= G.total) continue;
         uint32_t shard, pos0, lim;
         locate(G, grp, shard, pos0, lim);
@@ -1346,6 +1354,11 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WPE
     flush_shadow(A, n_shadow);
     if (COUNT) flush_work(A.work, MODE == 2 ? 4 : 3, wk);
 }
+template <int MODE, bool COUNT, bool GPOW>
+__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WPE_SQ))) void k_shade_quad(DScene S, LevelArgs A) {
+    __shared__ uint32_t lds_stack[RT_QSTACK * 16];
+    shade_quad_body<MODE, COUNT, GPOW>(S, A, lds_stack, blockIdx.x, gridDim.x, false);
+}
 
 // Colour of pool node i once its children (one level deeper) are final.
 __device__ __forceinline__ V3 node_color(const DScene& S, const float4* __restrict__ node_a, const uint4* __restrict__ node_b,
@@ -1376,12 +1389,12 @@ __global__ __launch_bounds__(256) void k_set_frame_params(FrameParamsChunk p, ui
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_clear16; i += gridDim.x * 256) clear[i] = make_uint4(0, 0, 0, 0);
 }
 
-// Fold of one level (>= 1): finishes every node whose children were traced one level deeper.
-__global__ __launch_bounds__(256) void k_fold(DScene S, LevelArgs A) {
+// Fold of one level (>= 1): finishes every node whose children were traced one level deeper. Wave vwave of vwaves.
+__device__ __forceinline__ void fold_body(const DScene& S, const LevelArgs& A, uint32_t vwave, uint32_t vwaves) {
     const ShardView v = shard_view(A, A.level, A.level);
     const Groups G = make_groups<false>(v.start, v.cnt);
     const uint32_t lane = threadIdx.x & 63u;
-    for (uint32_t grp = blockIdx.x * 4u + (threadIdx.x >> 6); grp < G.total; grp += gridDim.x * 4u) {
+    for (uint32_t grp = vwave; grp < G.total; grp += vwaves) {
         uint32_t shard, pos, lim;
         locate(G, grp, shard, pos, lim);
         const uint32_t i = pos + lane;
@@ -1394,6 +1407,109 @@ __global__ __launch_bounds__(256) void k_fold(DScene S, LevelArgs A) {
             A.node_a[i] = a;
             A.node_b[i].w = b.w & ~NODE_FOLD;
         }
+    }
+}
+__global__ __launch_bounds__(256) void k_fold(DScene S, LevelArgs A) {
+    fold_body(S, A, blockIdx.x * 4u + (threadIdx.x >> 6), gridDim.x * 4u);
+}
+
+// ---- the tail of the recursion in ONE launch --------------------------------------------------------------------
+// The deep levels of a frame hold a few thousand rays, then a few dozen (bunny_1080p: 4753, 3327, 636, 174, 40, 20, 17,
+// 8 at levels 3..10). One launch per level for the closest hits, a share of two shade launches and a fold launch each
+// make a chain of ~25 dependent launches that lasts as long as the rest of the frame (one frame at a time: levels 3..10
+// 217 us, the last light loops 60 us, the folds 90 us of 0.75 ms) while the chip is idle. k_tail runs levels
+// lv_first..lv_last in one launch of a few hundred small workgroups that are all resident at once:
+//   * the first half of the workgroups ("E") finds the closest hits level by level (one ray per quad, the body of
+//     k_extend_quad<1, true>), with a grid barrier among themselves where a launch boundary was: an arrival counter in
+//     device memory (one per pass, cleared with the pass counters), phase p is over when it reaches p x n_e;
+//   * the other half ("S") runs the light loops (the body of k_shade_quad<0>) of every level the counter says is complete,
+//     next to the E workgroups' deeper levels - nothing but the fold waits for them - and then arrives at a second counter;
+//   * the E workgroups wait for that one and fold the levels deepest first (k_fold's body), a barrier per level.
+// Visibility: every wave's stores are complete (workgroup-scope release: they are in the XCD's L2) before its
+// workgroup's barrier; thread 0 then releases at agent scope (L2 write-back: the workgroups sit on different XCDs) and
+// bumps the counter; a waiting workgroup's thread 0 polls it with agent-scope loads, and after the workgroup barrier
+// every wave acquires at agent scope (L1 / non-local L2 lines dropped). The level counters are atomics (L2).
+// Exit condition every wave reaches: the grid is far smaller than what the chip holds (256 workgroups of 4 waves, 16 KB
+// LDS), so every workgroup becomes resident as soon as other launches' waves retire; a poll that still sees no
+// progress after RT_TAIL_SPIN_LIMIT rounds (~1 s) raises `abort`, which every poll loop reads, flags the pass as
+// overflowed (the frame is reported as failed / re-run by the host, never silently wrong) and all workgroups return.
+#define RT_TAIL_WG_WAVES 4u
+#define RT_TAIL_SPIN_LIMIT (1u << 20)
+__device__ __forceinline__ bool tail_poll(uint32_t* ctr, uint32_t target, uint32_t* abort_flag, uint32_t* overflow) {      // one thread
+    for (uint32_t spins = 0;; ++spins) {
+        if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
+        if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+        if (spins > RT_TAIL_SPIN_LIMIT) {
+            __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(4);
+    }
+}
+// All threads of the workgroup. `arrive` (or null): counter to bump once this workgroup's stores are visible; `wait`
+// (or null): counter to poll until it reaches `target`. Returns false when the launch was aborted.
+__device__ __forceinline__ bool tail_sync(uint32_t* arrive, uint32_t* wait, uint32_t target, uint32_t* abort_flag, uint32_t* overflow,
+                                          uint32_t* lds_ok) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (arrive) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        *lds_ok = (!wait || tail_poll(wait, target, abort_flag, overflow)) ? 1u : 0u;
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return *lds_ok != 0u;
+}
+template <bool GPOW>
+__global__ __launch_bounds__(64 * RT_TAIL_WG_WAVES) __attribute__((amdgpu_waves_per_eu(4))) void k_tail(DScene S, LevelArgs A, int lv_first, int lv_last, uint32_t* bar) {
+    __shared__ uint32_t lds_stacks[RT_TAIL_WG_WAVES][RT_QSTACK * 16];
+    __shared__ uint32_t lds_ok;
+    const uint32_t wave = threadIdx.x >> 6;
+    uint32_t* lds = lds_stacks[wave];
+    const uint32_t n_e = gridDim.x >> 1, n_s = gridDim.x - n_e;      // workgroups per role
+    uint32_t* arrive_e = bar, * done_s = bar + 1, * abort_flag = bar + 2;
+    if (blockIdx.x < n_e) {
+        const uint32_t vb = blockIdx.x * RT_TAIL_WG_WAVES + wave, vg = n_e * RT_TAIL_WG_WAVES;
+        uint32_t phase = 0;
+        // diagnostics (RT_TAIL_LOG): workgroup 0 and the last E workgroup log {phase start, work done, barrier passed} in 10-ns ticks
+        uint4* log = (A.wave_log && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == n_e - 1)) ? A.wave_log + (blockIdx.x ? 64 : 0) : nullptr;
+        for (int lv = lv_first; lv <= lv_last; ++lv) {
+            const unsigned long long t0 = log ? wall_clock64() : 0ull;
+            A.level = lv; A.level_hi = lv;
+            extend_quad_body<1, true, false>(S, A, lds, vb, vg, true);
+            const unsigned long long t1 = log ? wall_clock64() : 0ull;
+            ++phase;
+            if (!tail_sync(arrive_e, arrive_e, phase * n_e, abort_flag, A.overflow, &lds_ok)) return;
+            if (log) log[phase] = make_uint4((uint32_t)t0, (uint32_t)t1, (uint32_t)wall_clock64(), (uint32_t)lv);
+        }
+        {
+            const unsigned long long t0 = log ? wall_clock64() : 0ull;
+            if (!tail_sync(nullptr, done_s, n_s, abort_flag, A.overflow, &lds_ok)) return;
+            if (log) log[32] = make_uint4((uint32_t)t0, (uint32_t)t0, (uint32_t)wall_clock64(), 99u);
+        }
+        for (int lv = lv_last - 1; lv >= lv_first; --lv) {
+            const unsigned long long t0 = log ? wall_clock64() : 0ull;
+            A.level = lv; A.level_hi = lv;
+            fold_body(S, A, vb, vg);
+            const unsigned long long t1 = log ? wall_clock64() : 0ull;
+            ++phase;
+            if (lv > lv_first && !tail_sync(arrive_e, arrive_e, phase * n_e, abort_flag, A.overflow, &lds_ok)) return;
+            if (log) log[phase] = make_uint4((uint32_t)t0, (uint32_t)t1, (uint32_t)wall_clock64(), (uint32_t)(100 + lv));
+        }
+    } else {
+        const uint32_t vb = (blockIdx.x - n_e) * RT_TAIL_WG_WAVES + wave, vg = n_s * RT_TAIL_WG_WAVES;
+        // (level by level: every S wave must cut the same range into the same groups, so the range cannot depend on how far
+        // each of them sees the E workgroups have come)
+        for (int lv = lv_first; lv <= lv_last; ++lv) {
+            if (!tail_sync(nullptr, arrive_e, (uint32_t)(lv - lv_first + 1) * n_e, abort_flag, A.overflow, &lds_ok)) return;
+            A.level = lv; A.level_hi = lv;
+            shade_quad_body<0, false, GPOW>(S, A, lds, vb, vg, true);
+        }
+        tail_sync(done_s, nullptr, 0u, abort_flag, A.overflow, &lds_ok);
     }
 }
 
@@ -1731,6 +1847,10 @@ void launch_set_frame_params(const FrameParamsBatch& p, uint32_t n_frames, Frame
         for (uint32_t i = n; i < RT_FP_CHUNK; ++i) c.f[i] = p.f[f0];
         hipLaunchKernelGGL(k_set_frame_params, dim3(f0 ? 1u : grid), dim3(256), 0, st, c, n, dst + f0, static_cast<uint4*>(clear), f0 ? 0u : n16);
     }
+}
+void launch_tail(const DScene& S, const LevelArgs& A, int lv_first, int lv_last, uint32_t* bar, uint32_t workgroups, hipStream_t st) {
+    if (S.generic_pow) hipLaunchKernelGGL((k_tail<true>), dim3(workgroups), dim3(64 * RT_TAIL_WG_WAVES), 0, st, S, A, lv_first, lv_last, bar);
+    else hipLaunchKernelGGL((k_tail<false>), dim3(workgroups), dim3(64 * RT_TAIL_WG_WAVES), 0, st, S, A, lv_first, lv_last, bar);
 }
 void launch_fold(const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st) {
     hipLaunchKernelGGL(k_fold, dim3(grid), dim3(256), 0, st, S, A);

@@ -298,33 +298,39 @@ def test_traversal_forms_agree(spp_grid):
     """Every way the library can take a frame through a mesh gives the same bytes and ray counts: level 0 by marks +
     quads (RT_PACKET=0), as 64-ray packets (1), packets at the deeper levels too (2); bounce levels as per-lane kernels
     + queues + resuming quads (RT_LARGE_THR=0: every level "large"), as one quad launch per level (huge threshold), or
-    as per-lane kernels whose quads serve the rays that reach the mesh (RT_SERVE=1).
+    as per-lane kernels whose quads serve the rays that reach the mesh (RT_SERVE=1); the deep levels one launch each
+    (RT_TAIL=0) or all of them - closest hits, light loops, folds - in one single-workgroup launch (k_tail: from level 1
+    on with a huge threshold, from where the levels hold <= 300 rays with RT_TAIL=300).
     The defaults pick among these by samples per pixel and level size; test_frame_parity pins the default to the
     oracle."""
     import os
     fs = wl.scene_bunny(10, third="glass2")
     cam, p = reference_camera(320, 240), Params(max_depth=6, aa=wl.aa_grid(spp_grid) if spp_grid > 1 else ())
-    saved = {k: os.environ.get(k) for k in ("RT_PACKET", "RT_LARGE_THR", "RT_SERVE", "RT_SPLIT_SMALL")}
+    saved = {k: os.environ.get(k) for k in ("RT_PACKET", "RT_LARGE_THR", "RT_SERVE", "RT_SPLIT_SMALL", "RT_TAIL")}
     frames = {}
     try:
-        for packet, thr, serve, split in (("0", "0", "0", "1"), ("0", "1000000000", "0", "1"), ("1", "0", "0", "1"),
-                                          ("1", "1000000000", "0", "1"), ("1", "1000000000", "1", "1"),
-                                          ("1", "1000000000", "0", "0"), ("2", "0", "0", "1"), ("2", "1000000000", "0", "1")):
+        for packet, thr, serve, split, tail in (
+                ("0", "0", "0", "1", "0"), ("0", "1000000000", "0", "1", "0"), ("1", "0", "0", "1", "0"),
+                ("1", "1000000000", "0", "1", "0"), ("1", "1000000000", "1", "1", "0"), ("1", "1000000000", "0", "0", "0"),
+                ("2", "0", "0", "1", "0"), ("2", "1000000000", "0", "1", "0"),
+                ("1", "1000000000", "0", "1", "1000000000"), ("1", "1000000000", "0", "1", "300"),
+                ("1", "1000000000", "1", "1", "300"), ("0", "0", "0", "1", "300"), ("2", "0", "0", "1", "300")):
             os.environ["RT_PACKET"] = packet            # read when the scene is created
+            os.environ["RT_TAIL"] = tail                # read at every call: levels of at most this many rays go to k_tail
             os.environ["RT_LARGE_THR"] = thr            # read at every call
             os.environ["RT_SERVE"] = serve              # bounce levels one ray per lane with quad service / one ray per quad
             os.environ["RT_SPLIT_SMALL"] = split        # small levels shaded per lane + resuming quads / one quad launch per run
             dev = DeviceScene(fs)
             dev.render(cam, p)                          # (the second frame of a scene knows its level sizes)
             img, st = dev.render(cam, p)
-            frames[(packet, thr, serve, split)] = (img, st.trace_calls, st.shadow_rays, list(st.level_rays))
+            frames[(packet, thr, serve, split, tail)] = (img, st.trace_calls, st.shadow_rays, list(st.level_rays))
     finally:
         for k, v in saved.items():
             if v is None:
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
-    base = frames[("1", "1000000000", "0", "1")]
+    base = frames[("1", "1000000000", "0", "1", "0")]
     for key, f in frames.items():
         assert np.array_equal(f[0], base[0]), key
         assert f[1:] == base[1:], key

@@ -34,4 +34,6 @@ else:
     else:
         for _ in range(n):
             dev.render_device(cam, p, frame.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+            if os.environ.get("ONE_FRAME_SYNC"):      # one frame at a time: wait for it (latency timelines)
+                dev.status()
 torch.cuda.synchronize()
