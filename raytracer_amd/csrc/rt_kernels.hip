@@ -325,6 +325,12 @@ __device__ __forceinline__ void quad_traverse(const DScene& S, uint32_t root, bo
 // lane only ever sees the triangles of leaves whose box its own ray hit or, superfluously, did not - the accepted hit
 // is still the lexicographic minimum of (t, original face index) over the triangles its ray hits (closest), or
 // "some triangle with EPS < t < tmax" (ANY).
+// v_writelane_b32: lane `lane` (wave-uniform, < 64) of v := value (wave-uniform); one VALU instruction
+__device__ __forceinline__ int write_lane(int v, uint32_t value, uint32_t lane) {
+    const int sv = __builtin_amdgcn_readfirstlane((int)value), sl = __builtin_amdgcn_readfirstlane((int)lane);      // (no-ops on scalars)
+    asm("v_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(sv), "{m0}"(sl));      // (one SGPR per VALU instruction: the lane goes through M0)
+    return v;
+}
 template <bool ANY, bool COUNT>
 __device__ __forceinline__ void packet_traverse(const DScene& S, uint32_t root, bool have, const Ray& ray, float tmax,
                                                 QuadHit& out, Work& wk) {
@@ -334,9 +340,9 @@ __device__ __forceinline__ void packet_traverse(const DScene& S, uint32_t root, 
     uint32_t face = 0xFFFFFFFFu;
     bool live = have;                       // ANY: cleared once the lane's ray is occluded
     int stack = 0;                          // lane k = stack entry k
-    const uint32_t lane = lane_id();
     uint32_t sp = 0;
-    uint32_t cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)(__builtin_amdgcn_ballot_w64(have) ? root : RT_DONE));   // RT_NO_CHILD == RT_DONE
+    unsigned long long live_m = __builtin_amdgcn_ballot_w64(have);      // `live` as a scalar (ANY: shrinks at the leaves)
+    uint32_t cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)(live_m ? root : RT_DONE));   // RT_NO_CHILD == RT_DONE
     while (cur != RT_DONE) {
         if (!(cur & RT_LEAF_BIT)) {
             const RT_CONSTANT u32x4* np = (const RT_CONSTANT u32x4*)(const void*)(S.nodes) + 8u * (size_t)cur;
@@ -354,20 +360,30 @@ __device__ __forceinline__ void packet_traverse(const DScene& S, uint32_t root, 
                 ref[c] = __float_as_uint(a.w);
                 bool h;
                 const float tn = slab(a.x, a.y, a.z, b.x, b.y, b.z, inv, ood, cull, h);
-                const unsigned long long m = __builtin_amdgcn_ballot_w64(h && live && ref[c] != RT_NO_CHILD);
+                // (the ballot of the comparison itself, masked by scalars: a ballot of `h && live && ...` goes through a VGPR)
+                unsigned long long m = __builtin_amdgcn_ballot_w64(h) & live_m;
+                if (ref[c] == RT_NO_CHILD) m = 0;
                 // distance of the first ray that hits the child (tn >= 0: its bits order like its value); none: last
                 const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(tn), (__ffsll((long long)m) - 1) & 63);
                 key[c] = m ? first : 0xFFFFFFFFu;
             }
+            // (Measured and not kept: the packet walked once per direction OCTANT of its rays, so that the entering / leaving
+            // plane of each axis is known and slab()'s six min/max per box fall away - with the planes picked by scalar selects
+            // 0.301 -> 0.310 ms per frame, with one instantiation of the box tests per octant 0.327: an SALU instruction costs
+            // a SIMD about as much issue time as a VALU min/max - one scalar unit serves the CU's four SIMDs,
+            // tools/valu_rate.hip - and both forms pushed more scalars into spill lanes.)
             // sort the four (key, ref) pairs, all wave-uniform: 5 compare-exchanges
 #define RT_CSWAP(i, j) { const bool sw = key[j] < key[i]; const uint32_t k0_ = sw ? key[j] : key[i], k1_ = sw ? key[i] : key[j]; \
                          const uint32_t r0_ = sw ? ref[j] : ref[i], r1_ = sw ? ref[i] : ref[j]; key[i] = k0_; key[j] = k1_; ref[i] = r0_; ref[j] = r1_; }
             RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
 #undef RT_CSWAP
             // the farthest goes in first, the nearest is visited next
-            if (key[3] != 0xFFFFFFFFu) { stack = lane == sp ? (int)ref[3] : stack; ++sp; }
-            if (key[2] != 0xFFFFFFFFu) { stack = lane == sp ? (int)ref[2] : stack; ++sp; }
-            if (key[1] != 0xFFFFFFFFu) { stack = lane == sp ? (int)ref[1] : stack; ++sp; }
+            // (one v_writelane per entry, written whether the child was hit or not: an entry that was not hit lands above the
+            // top of the stack - sp <= 63, the builders bound the traversal stack by RT_QSTACK - 1 pending entries - and is
+            // overwritten by the next push)
+            stack = write_lane(stack, ref[3], sp); sp += key[3] != 0xFFFFFFFFu ? 1u : 0u;
+            stack = write_lane(stack, ref[2], sp); sp += key[2] != 0xFFFFFFFFu ? 1u : 0u;
+            stack = write_lane(stack, ref[1], sp); sp += key[1] != 0xFFFFFFFFu ? 1u : 0u;
             if (key[0] != 0xFFFFFFFFu) cur = ref[0];
             else if (sp) { --sp; cur = (uint32_t)__builtin_amdgcn_readlane(stack, (int)sp); }
             else cur = RT_DONE;
@@ -401,7 +417,8 @@ __device__ __forceinline__ void packet_traverse(const DScene& S, uint32_t root, 
                     }
                 }
             }
-            if (ANY && __builtin_amdgcn_ballot_w64(live) == 0) cur = RT_DONE;
+            if (ANY) live_m = __builtin_amdgcn_ballot_w64(live);
+            if (ANY && live_m == 0) cur = RT_DONE;
             else if (sp) { --sp; cur = (uint32_t)__builtin_amdgcn_readlane(stack, (int)sp); }
             else cur = RT_DONE;
         }
