@@ -161,6 +161,16 @@ int rt_render(rt_scene* scene, const rt_camera* cam, const rt_params* params,
               uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
               uint8_t* bgr_out, rt_stats* stats);
 
+/* rt_render with a progress report. Replaces: the per-pixel `++finPix` of render() (reference src/raytracer.cpp:450)
+ * that the reference's main thread turns into its pix/s line (src/raytracer.cpp:217-225). `progress(user, done, total)`
+ * is called on the calling thread after every pass of the frame (a frame of up to 2^23 samples is one pass; an 8K frame
+ * at 64 samples per pixel is 254) with the pixels of the rectangle finished so far, and once more with done == total
+ * when the bytes are in bgr_out. progress == NULL: rt_render. */
+typedef void (*rt_progress_fn)(void* user, uint64_t pixels_done, uint64_t pixels_total);
+int rt_render_progress(rt_scene* scene, const rt_camera* cam, const rt_params* params,
+                       uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
+                       uint8_t* bgr_out, rt_stats* stats, rt_progress_fn progress, void* user);
+
 /* Same as rt_render but the framebuffer is a DEVICE pointer (same full-image BGR8 layout) and the call
  * is asynchronous on `stream` (a hipStream_t, or NULL for the scene's own stream) unless stats != NULL.
  * Replaces: render() when the caller keeps frames on the GPU (multi-GPU gather, encoders). */
@@ -252,6 +262,30 @@ int rt_untile_batch_device(int device, uint32_t imWidth, uint32_t imHeight, uint
                            uint32_t n_parts, uint32_t part_stride_tiles, uint32_t n_frames,
                            uint64_t in_frame_stride_bytes, uint64_t out_frame_stride_bytes,
                            const uint8_t* d_tiles_all, uint8_t* d_bgr_out, void* stream);
+
+/* One frame on several GPUs of ONE process. Replaces: the worker pool of thread_render() (reference
+ * src/raytracer.cpp:577-627: fixed tiles handed to workers that write into one shared img) for a C/C++ caller that has
+ * more than one GPU and no launcher. The scene is replicated (one rt_scene per entry of `devices`; a device may be
+ * listed more than once), 32x32-pixel tiles are dealt round-robin (rt_render_tiles_device), the parts' tile buffers
+ * are gathered on devices[0] by peer copies (hipMemcpyPeerAsync: direct xGMI transfers, each peer over its own link)
+ * and scattered into the row-major frame there (rt_untile_device). The frame equals the one-GPU frame byte for byte.
+ * `flags` as rt_scene_create_ex. (A one-process-per-GPU job uses the same entry points with a collective as the
+ * exchange: bench.py, INTEGRATION.md.) */
+#define RT_MULTI_MAX_DEVICES 64
+typedef struct rt_multi rt_multi;
+int rt_multi_create(const rt_flat_scene* scene, const int* devices, uint32_t n_devices, uint32_t flags, rt_multi** out);
+void rt_multi_destroy(rt_multi* multi);
+uint32_t rt_multi_parts(const rt_multi* multi);                    /* n_devices */
+rt_scene* rt_multi_scene(const rt_multi* multi, uint32_t part);    /* part's replica (its stream, status, BVH info) */
+/* render() of the WHOLE image (reference src/raytracer.cpp:422-463 with x_start = y_start = 0) into the caller's host
+ * buffer, the reference's BGR8 layout. Synchronous. stats (may be NULL): the parts' counters summed; with stats the
+ * parts run one after the other. A frame whose ray trees outgrow a replica's pool is rendered again with smaller passes. */
+int rt_multi_render(rt_multi* multi, const rt_camera* cam, const rt_params* params, uint8_t* bgr_out, rt_stats* stats);
+/* The same into a DEVICE buffer on devices[0], asynchronous (unless stats != NULL): the frame is complete when
+ * rt_multi_status returns, or for work ordered behind the stream of rt_multi_scene(multi, 0). */
+int rt_multi_render_device(rt_multi* multi, const rt_camera* cam, const rt_params* params, uint8_t* d_bgr_out, rt_stats* stats);
+/* Waits for all parts; RT_OK or the first failing part's rt_scene_status. */
+int rt_multi_status(rt_multi* multi);
 
 /* Unit entry points used by the parity tests (each runs the same device functions the renderer uses). */
 

@@ -112,7 +112,11 @@ EXPORTS = [
     "rt_tiles_owned", "rt_untile_device", "rt_untile_batch_device", "rt_cast_rays", "rt_intersect", "rt_occluded", "rt_trace",
     "rt_intersect_form", "rt_occluded_form", "rt_trace_form", "rt_scene_set_pass_samples",
     "rt_scene_bvh_info", "rt_bvh_check", "rt_scene_bvh_check", "rt_scene_status", "rt_scene_stream", "rt_set_count_work", "rt_get_work", "rt_last_error", "rt_version",
+    "rt_render_progress", "rt_multi_create", "rt_multi_destroy", "rt_multi_parts", "rt_multi_scene", "rt_multi_render", "rt_multi_render_device",
+    "rt_multi_status",
 ]
+
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_uint64)
 
 HOST_EXPORTS = [
     "rt_host_camera_make", "rt_host_plane_make", "rt_host_mat3_rotation", "rt_host_bbvol", "rt_host_model_load_ply",
@@ -179,6 +183,18 @@ def load(path=None):
     lib.rt_get_work.argtypes = [vp, C.c_int, C.POINTER(rt_work)]
     lib.rt_last_error.restype = C.c_char_p
     lib.rt_version.restype = C.c_char_p
+    lib.rt_render_progress.argtypes = [vp, C.POINTER(rt_camera), C.POINTER(rt_params), u32, u32, u32, u32,
+                                       C.POINTER(C.c_uint8), C.POINTER(rt_stats), PROGRESS_FN, vp]
+    lib.rt_multi_create.argtypes = [C.POINTER(rt_flat_scene), C.POINTER(C.c_int), u32, u32, C.POINTER(vp)]
+    lib.rt_multi_destroy.argtypes = [vp]
+    lib.rt_multi_destroy.restype = None
+    lib.rt_multi_parts.argtypes = [vp]
+    lib.rt_multi_parts.restype = u32
+    lib.rt_multi_scene.argtypes = [vp, u32]
+    lib.rt_multi_scene.restype = C.c_void_p
+    lib.rt_multi_render.argtypes = [vp, C.POINTER(rt_camera), C.POINTER(rt_params), C.POINTER(C.c_uint8), C.POINTER(rt_stats)]
+    lib.rt_multi_render_device.argtypes = [vp, C.POINTER(rt_camera), C.POINTER(rt_params), vp, C.POINTER(rt_stats)]
+    lib.rt_multi_status.argtypes = [vp]
     if path is None:
         _lib = lib
     return lib

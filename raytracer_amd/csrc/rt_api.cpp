@@ -36,6 +36,7 @@ void rt_set_error(const char* fmt, ...) {
         hipError_t e_ = (expr);                                                                    \
         if (e_ != hipSuccess) {                                                                    \
             rt_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            (void)hipGetLastError();      /* reported here: must not resurface in a later call's launch check */ \
             return RT_ERR_DEVICE;                                                                  \
         }                                                                                          \
     } while (0)
@@ -110,6 +111,7 @@ struct rt_scene {
     uint8_t* d_frame = nullptr; size_t frame_bytes = 0;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     std::vector<hipEvent_t> ev_pool;
+    std::vector<hipEvent_t> ev_pass;     // rt_render_progress: one per pass of the frame, recorded behind its k_resolve
     bool count_work = false;
     rt_work last_work[RT_N_KINDS]{};   // RT_K_* kernels
     int last_overflow = 0;
@@ -147,6 +149,7 @@ static int free_scene(rt_scene* s) {
     if (s->ev_begin) hipEventDestroy(s->ev_begin);
     if (s->ev_end) hipEventDestroy(s->ev_end);
     for (hipEvent_t e : s->ev_pool) hipEventDestroy(e);
+    for (hipEvent_t e : s->ev_pass) hipEventDestroy(e);
     for (hipEvent_t e : s->ev_sync) if (e) hipEventDestroy(e);
     for (hipStream_t st : s->shade_stream) if (st) hipStreamDestroy(st);
     if (s->stream) hipStreamDestroy(s->stream);
@@ -477,6 +480,8 @@ struct FrameJob {
     uint32_t launches_by[RT_N_KINDS];
     uint32_t n_pass_used;
     uint32_t large_mask;     // bit k: level k runs as per-lane kernel + queue (expect_large at the start of the frame)
+    rt_progress_fn progress; // synchronous frames: called as the passes complete (rt_render_progress)
+    void* progress_user;
 };
 
 // Waits for the stream and adds the recorded event pairs to the job's per-kind sums; the events are then reused.
@@ -810,6 +815,14 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
         // level sizes of this pass -> scheduling hint of the next one (no sync; see h_hint)
         HIP_TRY(hipMemcpyAsync(s->h_hint + size_t(slot) * RT_SHARDS, pc->sc, sizeof(ShardCounters) * RT_SHARDS, hipMemcpyDeviceToHost, sa));
         if (recs) recs->push_back({px0 + done, cnt, slot});
+        if (J.progress && recs) {       // event number = index of the pass in recs
+            while (s->ev_pass.size() < recs->size()) {
+                hipEvent_t e;
+                HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                s->ev_pass.push_back(e);
+            }
+            HIP_TRY(hipEventRecord(s->ev_pass[recs->size() - 1], sa));
+        }
     }
     return RT_OK;
 }
@@ -826,7 +839,8 @@ static void learn_from_overflow(rt_scene* s, uint32_t full_px) {
 // noalloc: the workspace is the static array of rt_kernels.hip (a pass of RT_NOALLOC_PASS_SAMPLES), nothing is
 // allocated, grown or freed; asynchronous only.
 static int render_frame(rt_scene* s, const rt_camera* cam, uint32_t n_frames, const rt_params* prm, const PixelMap& pm,
-                        uint8_t* d_out, uint64_t out_stride, hipStream_t st, rt_stats* stats, bool sync, bool noalloc = false) {
+                        uint8_t* d_out, uint64_t out_stride, hipStream_t st, rt_stats* stats, bool sync, bool noalloc = false,
+                        rt_progress_fn progress = nullptr, void* progress_user = nullptr) {
     HIP_TRY(hipSetDevice(s->device));
     const uint32_t spp = 1 + prm->n_aa;
     const uint64_t frame_px = uint64_t(pm.n_owned) * pm.tile_w * pm.tile_h;
@@ -857,6 +871,7 @@ static int render_frame(rt_scene* s, const rt_camera* cam, uint32_t n_frames, co
     if (s->packet_auto && s->n_models) s->d.packet = spp >= 16 ? 2u : 1u;
     FrameJob J{};
     J.s = s; J.st = st; J.d_out = d_out; J.timed = stats != nullptr;
+    J.progress = sync ? progress : nullptr; J.progress_user = progress_user;
     LevelArgs& B = J.base;
     std::memset(&B, 0, sizeof B);
     B.max_depth = prm->max_depth;
@@ -967,8 +982,18 @@ static int render_frame(rt_scene* s, const rt_camera* cam, uint32_t n_frames, co
     size_t checked = 0;
     uint32_t retries = 0;
     std::vector<PassRec> final_recs;
+    const size_t first_passes = recs.size();      // the frame's own passes; what follows them re-runs overflowed ones
+    uint64_t px_done = 0;
     while (checked < recs.size()) {
         const size_t upto = recs.size();
+        if (J.progress)      // pixels of the frame's passes as they complete (a pass that is re-run later was counted once)
+            for (size_t i = checked; i < upto; ++i) {
+                HIP_TRY(hipEventSynchronize(s->ev_pass[i]));
+                if (i < first_passes) {
+                    px_done = std::min<uint64_t>(total_px, px_done + recs[i].npx);
+                    if (px_done < total_px) J.progress(J.progress_user, px_done, total_px);      // (the last one: when the frame is good, below)
+                }
+            }
         HIP_TRY(hipMemcpyAsync(s->h_counters, s->d_counters, sizeof(PassCounters) * J.n_pass_used, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         for (size_t i = checked; i < upto; ++i) {
@@ -1116,6 +1141,13 @@ extern "C" int rt_render_device_noalloc(rt_scene* s, const rt_camera* cam, const
 
 extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_params* prm, uint32_t x0, uint32_t y0, uint32_t w,
                          uint32_t h, uint8_t* bgr, rt_stats* stats) {
+    return rt_render_progress(s, cam, prm, x0, y0, w, h, bgr, stats, nullptr, nullptr);
+}
+
+// rt_render that reports how far it is: progress(user, pixels done, pixels of the rectangle) after every pass of the
+// frame (a frame of up to 8 M samples is one pass) and once more, with done == total, when the bytes are in bgr.
+extern "C" int rt_render_progress(rt_scene* s, const rt_camera* cam, const rt_params* prm, uint32_t x0, uint32_t y0, uint32_t w,
+                                  uint32_t h, uint8_t* bgr, rt_stats* stats, rt_progress_fn progress, void* user) {
     if (!s || !bgr) { rt_set_error("null argument"); return RT_ERR_INVALID; }
     int rc = check_params(cam, prm);
     if (rc != RT_OK) return rc;
@@ -1129,7 +1161,15 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_params* prm
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_frame), need));
         s->frame_bytes = need;
     }
-    rc = render_frame(s, cam, 1, prm, rect_map(cam, x0, y0, w, h), s->d_frame, 0, s->stream, stats, true);
+    // (progress counts the pixels of the rectangle rounded up to whole 8x8 blocks, as the passes do; scaled back below)
+    struct Scale { rt_progress_fn fn; void* user; uint64_t rect_px, padded_px; } sc{progress, user, uint64_t(w) * h,
+                                                                                   uint64_t((w + 7u) & ~7u) * ((h + 7u) & ~7u)};
+    const rt_progress_fn scaled = [](void* u, uint64_t done, uint64_t) {
+        const Scale* c = static_cast<const Scale*>(u);
+        c->fn(c->user, std::min<uint64_t>(c->rect_px, done * c->rect_px / std::max<uint64_t>(c->padded_px, 1)), c->rect_px);
+    };
+    rc = render_frame(s, cam, 1, prm, rect_map(cam, x0, y0, w, h), s->d_frame, 0, s->stream, stats, true, false,
+                      progress ? scaled : nullptr, &sc);
     if (rc != RT_OK) return rc;
     finish_stats(stats, uint64_t(w) * h, 1 + prm->n_aa);
     const size_t pitch = size_t(cam->imWidth) * 3, off = (size_t(y0) * cam->imWidth + x0) * 3;
@@ -1138,6 +1178,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_params* prm
     else
         HIP_TRY(hipMemcpy2DAsync(bgr + off, pitch, s->d_frame + off, pitch, size_t(w) * 3, h, hipMemcpyDeviceToHost, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
+    if (progress) progress(user, uint64_t(w) * h, uint64_t(w) * h);
     return RT_OK;
 }
 

@@ -468,7 +468,7 @@ class Scene {
 public:
     Scene() = default;
     explicit Scene(const std::string& filename);          // YAML loader, raytracer_amd/host/scene_yaml.hpp
-    ~Scene() { if (dev_) rt_scene_destroy(dev_); }
+    ~Scene() { if (dev_) rt_scene_destroy(dev_); if (multi_) rt_multi_destroy(multi_); }
     Scene(const Scene&) = delete;
     Scene& operator=(const Scene&) = delete;
 
@@ -498,8 +498,27 @@ public:
         }
         return dev_;
     }
+    // The GPUs render() spreads a whole frame over (default: device 0 alone). No counterpart in the reference, whose
+    // workers are CPU threads (ref src/raytracer.cpp:577-627).
+    void setDevices(std::vector<int> devices) { invalidate(); devices_ = std::move(devices); }
+    const std::vector<int>& devices() const { return devices_; }
+    // The replicas on devices(), created on first use and kept until the scene changes.
+    rt_multi* multiScene() const {
+        if (!multi_) {
+            FlatSceneBuilder fb;
+            flatten(fb);
+            const rt_flat_scene fs = fb.view();
+            if (rt_multi_create(&fs, devices_.data(), uint32_t(devices_.size()), 0u, &multi_) != RT_OK) throw std::runtime_error(rt_last_error());
+        }
+        return multi_;
+    }
 private:
-    void invalidate() const { if (dev_) { rt_scene_destroy(dev_); dev_ = nullptr; } }
+    void invalidate() const {
+        if (dev_) { rt_scene_destroy(dev_); dev_ = nullptr; }
+        if (multi_) { rt_multi_destroy(multi_); multi_ = nullptr; }
+    }
+    std::vector<int> devices_;
+    mutable rt_multi* multi_ = nullptr;
     std::vector<std::unique_ptr<Primitive>> objects;
     std::vector<Light> lights;
     mutable rt_scene* dev_ = nullptr;
@@ -513,8 +532,10 @@ inline int& maxDepth() { static int d = 10; return d; }
 
 // Same signature and contract as the reference's render() (ref src/raytracer.cpp:422-463): writes the BGR8
 // bytes of rectangle [x_start, x_start+cW) x [y_start, y_start+cH) of the full-image buffer `img`,
-// adds the rectangle's pixel count to finPix when done and decrements thread_count. Throws on device errors
-// (the reference's render cannot fail).
+// adds the rectangle's pixels to finPix AS ITS PASSES COMPLETE (the reference: ++finPix per pixel, ref :450, read by
+// the main thread for its pix/s line, ref :217-225; a frame of up to 8 M samples is one pass) and decrements
+// thread_count. A scene with setDevices({...}) of more than one GPU renders whole-image calls on all of them.
+// Throws on device errors (the reference's render cannot fail).
 inline void render(ImageType* img, unsigned int x_start, unsigned int y_start, unsigned int cH, unsigned int cW,
                    const Camera& camera, const Scene& scene, const Color& background, unsigned int& finPix,
                    unsigned int& thread_count) {
@@ -526,8 +547,19 @@ inline void render(ImageType* img, unsigned int x_start, unsigned int y_start, u
     prm.max_depth = maxDepth();
     prm.n_aa = uint32_t(aa.size() / 2);
     prm.aa_xy = aa.data();
-    if (rt_render(scene.deviceScene(), &cam, &prm, x_start, y_start, cW, cH, img, nullptr) != RT_OK)
-        throw std::runtime_error(rt_last_error());
-    finPix += cW * cH;
+    const bool whole = x_start == 0 && y_start == 0 && cW == cam.imWidth && cH == cam.imHeight;
+    if (scene.devices().size() > 1 && whole) {
+        if (rt_multi_render(scene.multiScene(), &cam, &prm, img, nullptr) != RT_OK) throw std::runtime_error(rt_last_error());
+        finPix += cW * cH;
+    } else {
+        struct Progress { unsigned int* fin; unsigned int base; } pg{&finPix, finPix};
+        const rt_progress_fn cb = [](void* u, uint64_t done, uint64_t) {
+            Progress* g = static_cast<Progress*>(u);
+            *g->fin = g->base + static_cast<unsigned int>(done);
+        };
+        rt_scene* dev = scene.devices().empty() ? scene.deviceScene() : scene.deviceScene(scene.devices()[0]);
+        if (rt_render_progress(dev, &cam, &prm, x_start, y_start, cW, cH, img, nullptr, cb, &pg) != RT_OK)
+            throw std::runtime_error(rt_last_error());
+    }
     if (thread_count > 0) --thread_count;
 }

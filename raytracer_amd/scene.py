@@ -353,6 +353,49 @@ def bvh_check(flat):
     return out
 
 
+class MultiScene:
+    """rt_multi: the scene replicated on several GPUs of this process (a device may be listed more than once); whole
+    frames are rendered as round-robin tiles, gathered on devices[0] by peer copies. Fails loudly without the library or a GPU."""
+
+    def __init__(self, flat, devices, bvh="host"):
+        self.lib = cabi.load()
+        self.flat = flat
+        self.h = C.c_void_p()
+        devs = (C.c_int * len(devices))(*devices)
+        flags = {"host": 0, "device": cabi.RT_SCENE_BVH_DEVICE}[bvh]
+        cabi.check(self.lib, self.lib.rt_multi_create(C.byref(flat.c_struct()), devs, len(devices), flags, C.byref(self.h)))
+
+    def parts(self):
+        return int(self.lib.rt_multi_parts(self.h))
+
+    def render(self, cam, params, out=None, want_stats=True):
+        """rt_multi_render -> (H,W,3) uint8 BGR frame in host memory, summed rt_stats."""
+        if out is None:
+            out = np.zeros((cam.imHeight, cam.imWidth, 3), np.uint8)
+        st = rt_stats()
+        cabi.check(self.lib, self.lib.rt_multi_render(self.h, C.byref(cam), C.byref(params.c), cabi.u8ptr(out),
+                                                      C.byref(st) if want_stats else None))
+        return out, st
+
+    def render_device(self, cam, params, d_ptr):
+        """rt_multi_render_device (asynchronous): the frame into a device buffer on devices[0]; status() waits."""
+        cabi.check(self.lib, self.lib.rt_multi_render_device(self.h, C.byref(cam), C.byref(params.c), C.c_void_p(d_ptr), None))
+
+    def status(self):
+        cabi.check(self.lib, self.lib.rt_multi_status(self.h))
+
+    def close(self):
+        if self.h:
+            self.lib.rt_multi_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class DeviceScene:
     """rt_scene on one GPU. Fails loudly when the HIP library or a GPU is missing."""
 
@@ -392,6 +435,18 @@ class DeviceScene:
         st = rt_stats()
         cabi.check(self.lib, self.lib.rt_render(self.h, C.byref(cam), C.byref(params.c), x0, y0, w, h,
                                                 cabi.u8ptr(out), C.byref(st) if want_stats else None))
+        return out, st
+
+    def render_progress(self, cam, params, callback, rect=None, out=None):
+        """rt_render_progress: rt_render that calls callback(pixels_done, pixels_total) after every pass and at the end."""
+        W, H = cam.imWidth, cam.imHeight
+        if out is None:
+            out = np.zeros((H, W, 3), np.uint8)
+        x0, y0, w, h = rect if rect is not None else (0, 0, W, H)
+        st = rt_stats()
+        fn = cabi.PROGRESS_FN(lambda user, done, total: callback(int(done), int(total)))
+        cabi.check(self.lib, self.lib.rt_render_progress(self.h, C.byref(cam), C.byref(params.c), x0, y0, w, h,
+                                                         cabi.u8ptr(out), C.byref(st), fn, None))
         return out, st
 
     def render_device(self, cam, params, d_ptr, rect=None, stream=None, stats=None):

@@ -33,5 +33,10 @@ def test_example_renders_scene_file(tmp_path):
     rgb = np.frombuffer(b[len(head):], np.uint8).reshape(240, 320, 3)
     want, _ = DeviceScene(FlatScene.load_yaml(path)).render(reference_camera(320, 240), Params())
     assert np.array_equal(rgb[:, :, ::-1], want)
+    # the same frame spread over two replicas (Scene::setDevices -> rt_multi_render; the box has one GPU, named twice)
+    out2 = tmp_path / "frame2.ppm"
+    r = subprocess.run([APP, str(path), "-o", str(out2), "-w", "320", "-h", "240", "-devices", "0,0"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert out2.read_bytes() == b
     bad = subprocess.run([APP, str(tmp_path / "missing.yaml")], capture_output=True, text=True)
     assert bad.returncode == 1 and "could not be opened" in bad.stderr
