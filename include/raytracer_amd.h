@@ -329,10 +329,13 @@ int rt_trace_form(rt_scene* scene, int form, const rt_params* params, const floa
                   float* rgb_out, rt_stats* stats);
 
 /* Level-0 samples per pass: a frame with more samples is rendered in passes of whole pixels that reuse one
- * workspace (default 2^23; `samples` a power of two in [2^12, 2^26], 0 = the default). Waits for the scene's
- * frames in flight. Results never depend on it. No counterpart in the reference (its recursion needs no workspace);
- * for callers that bound the scene's HBM use (6 x 112 B per sample of a pass) and for the multi-pass parity tests. */
+ * workspace (`samples` a power of two in [2^12, 2^26], 0 = the default: the largest power of two up to 2^26 whose
+ * workspace - 6 x 112 B per sample - stays below a fifth of the device's memory, at least 2^23; 2^26 on an MI355X. Larger
+ * passes render faster; a scene that finds no room for its workspace falls back to smaller ones by itself). Waits for
+ * the scene's frames in flight. Results never depend on it. No counterpart in the reference (its recursion needs no
+ * workspace); for callers that bound the scene's HBM use and for the multi-pass parity tests. */
 int rt_scene_set_pass_samples(rt_scene* scene, uint32_t samples);
+uint32_t rt_scene_pass_samples(const rt_scene* scene);      /* the current value */
 
 /* BVH introspection for tests and the roofline's algorithmic bytes/flops. */
 typedef struct rt_bvh_info {

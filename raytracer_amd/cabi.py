@@ -113,7 +113,7 @@ EXPORTS = [
     "rt_intersect_form", "rt_occluded_form", "rt_trace_form", "rt_scene_set_pass_samples",
     "rt_scene_bvh_info", "rt_bvh_check", "rt_scene_bvh_check", "rt_scene_status", "rt_scene_stream", "rt_set_count_work", "rt_get_work", "rt_last_error", "rt_version",
     "rt_render_progress", "rt_multi_create", "rt_multi_destroy", "rt_multi_parts", "rt_multi_scene", "rt_multi_render", "rt_multi_render_device",
-    "rt_multi_status",
+    "rt_multi_status", "rt_scene_pass_samples",
 ]
 
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_uint64)
@@ -173,6 +173,8 @@ def load(path=None):
     lib.rt_occluded_form.argtypes = [vp, C.c_int, FP, FP, u32, C.POINTER(C.c_uint8)]
     lib.rt_trace_form.argtypes = [vp, C.c_int, C.POINTER(rt_params), FP, u32, FP, C.POINTER(rt_stats)]
     lib.rt_scene_set_pass_samples.argtypes = [vp, u32]
+    lib.rt_scene_pass_samples.argtypes = [vp]
+    lib.rt_scene_pass_samples.restype = u32
     lib.rt_scene_bvh_info.argtypes = [vp, C.POINTER(rt_bvh_info)]
     lib.rt_bvh_check.argtypes = [C.POINTER(rt_flat_scene), C.POINTER(rt_bvh_check_result)]
     lib.rt_scene_bvh_check.argtypes = [vp, C.POINTER(rt_flat_scene), C.POINTER(rt_bvh_check_result)]

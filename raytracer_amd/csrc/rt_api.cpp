@@ -57,12 +57,21 @@ struct PassCounters {                 // one per pass, zeroed by one memset per 
 #define RT_MAX_PASSES 1024
 #define RT_PASS_LOG2_MIN 12
 #define RT_PASS_LOG2_MAX 26
-// Level-0 samples per pass of a new scene: 8 M (RT_PASS_LOG2 in the environment for experiments). A property of the
-// scene (rt_scene::pass_samples, rt_scene_set_pass_samples), read when the scene is created.
+// Level-0 samples per pass of a new scene (RT_PASS_LOG2 in the environment for experiments). A property of the scene
+// (rt_scene::pass_samples, rt_scene_set_pass_samples), read when the scene is created, with its device current.
+// Larger passes are faster - the bounce levels of a pass are a chain of dependent launches whose sizes grow with it:
+// 4K 16 spp glass scene 38.2 ms per frame at 2^23, 36.6 at 2^24, 34.1 at 2^25, 32.0 at 2^26; 10 M-triangle field at 8K 64 spp
+// 634 / 614 / 609 ms - and cost 672 B of workspace per sample (5.4 GB at 2^23, 45 GB at 2^26). So: the largest power of
+// two up to 2^26 whose workspace stays below a fifth of the device's memory (2^26 on the 288 GB of an MI355X), at least
+// 2^23. A frame with fewer samples is one pass and allocates for what it has.
 static uint32_t default_pass_samples() {
-    const char* e = std::getenv("RT_PASS_LOG2");
-    const int k = e ? std::atoi(e) : 23;
-    return 1u << std::max(RT_PASS_LOG2_MIN, std::min(RT_PASS_LOG2_MAX, k));
+    if (const char* e = std::getenv("RT_PASS_LOG2")) return 1u << std::max(RT_PASS_LOG2_MIN, std::min(RT_PASS_LOG2_MAX, std::atoi(e)));
+    size_t free_b = 0, total_b = 0;
+    int k = 23;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+        while (k < RT_PASS_LOG2_MAX && (uint64_t(672) << (k + 1)) <= total_b / 5u) ++k;
+    else (void)hipGetLastError();
+    return 1u << k;
 }
 #define RT_POOL_FACTOR 6u             // node pool = 6x the pass size when materials bounce (level 0 + 5x for deeper levels)
 #define RT_MAX_TIMED 2048
@@ -368,6 +377,8 @@ extern "C" int rt_scene_set_pass_samples(rt_scene* s, uint32_t samples) {
     s->shrink_log2 = 0;
     return RT_OK;
 }
+
+extern "C" uint32_t rt_scene_pass_samples(const rt_scene* s) { return s ? s->pass_samples : 0u; }
 
 extern "C" int rt_scene_bvh_info(const rt_scene* s, rt_bvh_info* out) {
     if (!s || !out) { rt_set_error("null argument"); return RT_ERR_INVALID; }
@@ -680,7 +691,9 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
         // field 5.40 -> 5.22); a smaller pass keeps one ray per quad, whose waves are a quarter as long (one 1080p frame at
         // a time: 0.73 ms against 0.91 with quad service). RT_SERVE=0/1 overrides.
         const int serve_env = std::getenv("RT_SERVE") ? std::atoi(std::getenv("RT_SERVE")) : -1;
-        const bool serve = s->d.packet >= 1 && (serve_env >= 0 ? serve_env != 0 : (s->d.packet == 1 && A.n0 >= (4u << 20)));
+            // (Scenes with packets at every level, 16+ spp: their small bounce levels only from 32 M-sample passes on - 4K glass
+        // scene at 2^26 32.0 -> 31.0 ms, at 2^25 34.1 -> 33.1; 10 M-triangle field at 8K: 2^23 632 -> 673 ms, 2^26 the same.)
+        const bool serve = s->d.packet >= 1 && (serve_env >= 0 ? serve_env != 0 : (A.n0 >= (s->d.packet == 1 ? (4u << 20) : (32u << 20))));
         const bool split_small = std::getenv("RT_SPLIT_SMALL") ? std::atoi(std::getenv("RT_SPLIT_SMALL")) != 0 : true;
         auto shade_small = [&](int lo, int hi, int after) -> int {
             // (not where the per-lane kernels traverse meshes as packets at every level: the rays of a small bounce level
@@ -850,7 +863,7 @@ static int render_frame(rt_scene* s, const rt_camera* cam, uint32_t n_frames, co
     if (n_frames > 1 && frame_px * spp > 0xFFFFFFC0ull) { rt_set_error("frames of a batch are limited to 2^32 samples each"); return RT_ERR_LIMIT; }
     // The workspace is sized for the full pass; a scene whose ray trees outgrow the pool (learned from overflows, below
     // and in rt_scene_status) runs smaller passes in the same workspace: 2^k times the room per sample.
-    const uint32_t full_px = std::max<uint32_t>(64u, RT_PASS_SAMPLES / spp);
+    uint32_t full_px = std::max<uint32_t>(64u, RT_PASS_SAMPLES / spp);
     if (*s->h_overflow && s->last_overflow == -1) { s->last_overflow = 1; learn_from_overflow(s, full_px); }
     uint32_t pass_px = uint32_t(std::min<uint64_t>(total_px, std::max<uint32_t>(64u, full_px >> s->shrink_log2)));
     pass_px = (pass_px + 63u) & ~63u;
@@ -862,6 +875,14 @@ static int render_frame(rt_scene* s, const rt_camera* cam, uint32_t n_frames, co
         if (uint64_t(pass_px) * spp > RT_NOALLOC_PASS_SAMPLES) { rt_set_error("64 pixels of %u samples do not fit the static workspace", spp); return RT_ERR_LIMIT; }
     } else {
         rc = ensure_workspace(s, std::max(((uint32_t(std::min<uint64_t>(total_px, full_px)) + 63u) & ~63u) * spp, s->ws_min_n0));
+        // no room for passes that large (other scenes, other users of the device): smaller passes, down to the 2^23 default
+        while (rc == RT_ERR_DEVICE && s->pass_samples > (1u << 23) && uint64_t(pass_px) * spp > (1u << 23)) {
+            s->pass_samples >>= 1;
+            full_px = std::max<uint32_t>(64u, RT_PASS_SAMPLES / spp);
+            pass_px = uint32_t(std::min<uint64_t>(total_px, std::max<uint32_t>(64u, full_px >> s->shrink_log2)));
+            pass_px = (pass_px + 63u) & ~63u;
+            rc = ensure_workspace(s, std::max(((uint32_t(std::min<uint64_t>(total_px, full_px)) + 63u) & ~63u) * spp, s->ws_min_n0));
+        }
         if (rc != RT_OK) return rc;
     }
 

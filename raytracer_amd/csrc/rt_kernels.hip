@@ -233,20 +233,39 @@ struct QuadHit { float t, u, v; uint32_t face; };   // face == 0xFFFFFFFF: nothi
 // ANY = true : is there a face with EPS < t < tmax (the shadow test `hit && tmpdist < ldist`, raytracer.cpp:320-321);
 //              out.face != 0xFFFFFFFF then.
 // `qs` points at this quad's column of the LDS stack (stride 16 words). Called with all 64 lanes active.
-template <bool ANY, bool COUNT>
-__device__ __forceinline__ void quad_traverse(const DScene& S, uint32_t root, bool have, const Ray& ray, float tmax,
-                                              QuadHit& out, uint32_t* qs, Work& wk) {
-    const uint32_t lane = lane_id(), j = lane & 3u;
+// The traversal is resumable: its state is a QTrav (registers) plus the quad's LDS stack column, and quad_run can
+// return while some quads are still on their way (serve_traverse hands idle quads new rays then). cur == RT_DONE: done.
+struct QTrav {
+    uint32_t cur;
+    int sp;
+    float best, bu, bv;      // this LANE's best candidate
+    uint32_t face;
+    float tcull;             // the quad's culling distance
+    V3 inv, ood;
+};
+template <bool ANY>
+__device__ __forceinline__ void quad_begin(QTrav& t, uint32_t root, bool have, const Ray& ray, float tmax, uint32_t* qs) {
     // culling direction: a zero (or denormal) component is replaced by +-1e-30 so that lo*inv - o*inv keeps the sign of
     // lo - o instead of becoming inf - inf; only the box tests use it, the triangle test gets the ray as it is
-    const V3 inv = mk(safe_rcp(ray.d.x), safe_rcp(ray.d.y), safe_rcp(ray.d.z));
-    const V3 ood = mk(ray.o.x * inv.x, ray.o.y * inv.y, ray.o.z * inv.z);
-    float best = ANY ? tmax : FLT_MAX, bu = 0, bv = 0;      // this LANE's best candidate
-    uint32_t face = 0xFFFFFFFFu;
-    float tcull = best;                                      // the quad's culling distance
-    if (j == 0) qs[0] = RT_DONE;
-    int sp = 1;
-    uint32_t cur = have ? root : RT_DONE;      // RT_NO_CHILD == RT_DONE for an empty model
+    t.inv = mk(safe_rcp(ray.d.x), safe_rcp(ray.d.y), safe_rcp(ray.d.z));
+    t.ood = mk(ray.o.x * t.inv.x, ray.o.y * t.inv.y, ray.o.z * t.inv.z);
+    t.best = ANY ? tmax : FLT_MAX; t.bu = 0; t.bv = 0;
+    t.face = 0xFFFFFFFFu;
+    t.tcull = t.best;
+    if ((lane_id() & 3u) == 0) qs[0] = RT_DONE;
+    t.sp = 1;
+    t.cur = have ? root : RT_DONE;      // RT_NO_CHILD == RT_DONE for an empty model
+}
+// Steps every quad that is not done. keep_lanes == 0: until all are done. Otherwise also returns, between two leaves,
+// as soon as fewer than keep_lanes LANES (4 per quad) are still traversing.
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ void quad_run(const DScene& S, QTrav& t, const Ray& ray, float tmax, uint32_t* qs, uint32_t keep_lanes, Work& wk) {
+    const uint32_t lane = lane_id(), j = lane & 3u;
+    uint32_t cur = t.cur;
+    int sp = t.sp;
+    float best = t.best, bu = t.bu, bv = t.bv, tcull = t.tcull;
+    uint32_t face = t.face;
+    const V3 inv = t.inv, ood = t.ood;
     while (cur != RT_DONE) {
         while (!(cur & RT_LEAF_BIT)) {
             const float4* np = reinterpret_cast<const float4*>(S.nodes + cur) + j;
@@ -281,13 +300,13 @@ __device__ __forceinline__ void quad_traverse(const DScene& S, uint32_t root, bo
             if (j < cnt) {
                 const float4* tp = reinterpret_cast<const float4*>(S.leaves + start) + j;
                 const float4 q0 = tp[0], q1 = tp[4], q2 = tp[8];
-                float t, u, v;
-                if (tri_isect(f4xyz(q0), f4xyz(q1), f4xyz(q2), ray, t, u, v)) {
+                float tt, u, v;
+                if (tri_isect(f4xyz(q0), f4xyz(q1), f4xyz(q2), ray, tt, u, v)) {
                     const uint32_t f = __float_as_uint(q0.w);
                     if (ANY) {
-                        got = t < tmax;
-                    } else if (t < best || (t == best && f < face)) {
-                        best = t; bu = u; bv = v; face = f;
+                        got = tt < tmax;
+                    } else if (tt < best || (tt == best && f < face)) {
+                        best = tt; bu = u; bv = v; face = f;
                     }
                 }
             }
@@ -297,7 +316,16 @@ __device__ __forceinline__ void quad_traverse(const DScene& S, uint32_t root, bo
                 tcull = quad_min_f(best) * 1.000001f;
             }
         }
+        // (the lanes that are still in this loop are the ones that count)
+        if (keep_lanes && (uint32_t)__popcll(__ballot(cur != RT_DONE)) < keep_lanes) break;
     }
+    t.cur = cur; t.sp = sp; t.best = best; t.bu = bu; t.bv = bv; t.tcull = tcull; t.face = face;
+}
+// The quad's result once its traversal is done (identical in its four lanes).
+template <bool ANY>
+__device__ __forceinline__ void quad_result(const QTrav& t, QuadHit& out) {
+    float best = t.best, bu = t.bu, bv = t.bv;
+    uint32_t face = t.face;
     if (!ANY) {
         // the quad's winner: lexicographic minimum of (t, face) over its four lanes
         {
@@ -312,6 +340,14 @@ __device__ __forceinline__ void quad_traverse(const DScene& S, uint32_t root, bo
         }
     }
     out.t = best; out.u = bu; out.v = bv; out.face = face;
+}
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ void quad_traverse(const DScene& S, uint32_t root, bool have, const Ray& ray, float tmax,
+                                              QuadHit& out, uint32_t* qs, Work& wk) {
+    QTrav t;
+    quad_begin<ANY>(t, root, have, ray, tmax, qs);
+    quad_run<ANY, COUNT>(S, t, ray, tmax, qs, 0u, wk);
+    quad_result<ANY>(t, out);
 }
 
 // ---- packet traversal: the wave's (up to) 64 rays, one per lane, walk the tree TOGETHER --------------------------
@@ -427,37 +463,73 @@ __device__ __forceinline__ void packet_traverse(const DScene& S, uint32_t root, 
 }
 
 // ---- quad service: a per-lane kernel whose rays reach a mesh traverses it with its own quads ---------------------
-// The lanes that need the traversal (`need`) are served 16 at a time: quad q takes over the ray of the q-th needing
-// lane (10 cross-lane moves in, 4 out), the wave runs quad_traverse, the results go back to the lanes they belong
-// to. Everything else of the ray - analytic objects, Fresnel, Phong - stays one ray per lane, where a quad kernel
-// computes it four times over. For the bounce levels, whose rays have nothing in common (no packets) and mostly do
-// reach the mesh (so queueing them, which costs a round trip of their state through memory, does not pay).
-// `lds` = the wave's 16-column stack (RT_QSTACK x 16 words). Called with all 64 lanes active; same results as
-// quad_traverse on each ray.
+// The lanes that need the traversal (`need`) are served by the wave's 16 quads: a quad takes over the ray of the next
+// needing lane (7 cross-lane moves in), traverses it (quad_run) and leaves the result in that lane's LDS mailbox.
+// Quads do not wait for each other in batches: rays differ a lot in length (bounce rays of the 10 M-triangle field:
+// 18 node steps on average, 47 for the longest of 16 - lockstep batches kept the quads 38 % busy), so as soon as a
+// quarter of the quads have finished, the traversal pauses, the idle quads take the next rays, and it goes on. Everything else of the
+// ray - analytic objects, Fresnel, Phong - stays one ray per lane, where a quad kernel computes it four times over.
+// For the bounce levels, whose rays have nothing in common (no packets) and mostly do reach the mesh (so queueing
+// them, which costs a round trip of their state through memory, does not pay).
+// `lds` = RT_SERVE_LDS words: the wave's 16-column stack (RT_QSTACK x 16) and the mailboxes (4 words per lane). Called
+// with all 64 lanes active; same results as quad_traverse on each ray.
+#define RT_SERVE_LDS (RT_QSTACK * 16 + 256)
+#ifndef RT_SERVE_KEEP
+#define RT_SERVE_KEEP 12u      // quads: the traversal pauses for a refill when fewer are still busy (and rays are left)
+#endif
 __device__ __forceinline__ uint32_t select_bit(unsigned long long mask, uint32_t q);      // index of the q-th set bit (below)
 template <bool ANY, bool COUNT>
 __device__ __forceinline__ void serve_traverse(const DScene& S, uint32_t root, bool need, const Ray& ray, float tmax,
                                                QuadHit& out, uint32_t* lds, Work& wk) {
-    const uint32_t lane = lane_id(), quad = lane >> 2;
+    const uint32_t lane = lane_id(), quad = lane >> 2, j = lane & 3u;
+    uint32_t* qs = lds + quad;
+    uint32_t* mail = lds + RT_QSTACK * 16;
     out.face = 0xFFFFFFFFu; out.t = 0; out.u = 0; out.v = 0;
     const unsigned long long m = __builtin_amdgcn_ballot_w64(need);
     const uint32_t n = (uint32_t)__popcll(m);                                        // wave-uniform
-    const uint32_t my_rank = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));        // among the needing lanes
-    for (uint32_t base = 0; base < n; base += 16u) {
-        const uint32_t want = base + quad;
-        const bool have = want < n;
-        const int src = (int)(have ? select_bit(m, want) : lane);
-        Ray qr;
-        qr.o = mk(__shfl(ray.o.x, src), __shfl(ray.o.y, src), __shfl(ray.o.z, src));
-        qr.d = mk(__shfl(ray.d.x, src), __shfl(ray.d.y, src), __shfl(ray.d.z, src));
-        const float qt = ANY ? __shfl(tmax, src) : FLT_MAX;
-        QuadHit q;
-        q.face = 0xFFFFFFFFu; q.t = 0; q.u = 0; q.v = 0;
-        quad_traverse<ANY, COUNT>(S, root, have, qr, qt, q, lds + quad, wk);
-        const int from = (int)(((my_rank - base) & 15u) * 4u);
-        const uint32_t f = (uint32_t)__shfl((int)q.face, from);
-        const float t = ANY ? 0.0f : __shfl(q.t, from), u = ANY ? 0.0f : __shfl(q.u, from), v = ANY ? 0.0f : __shfl(q.v, from);
-        if (need && my_rank >= base && my_rank < base + 16u) { out.face = f; out.t = t; out.u = u; out.v = v; }
+    if (n == 0) return;
+    uint32_t next = 0;                   // needing lanes handed out so far (wave-uniform)
+    bool busy = false;                   // this quad is on a ray
+    uint32_t owner = lane;               // ... of this lane
+    Ray qr;
+    qr.o = mk(0, 0, 0); qr.d = mk(0, 0, 0);
+    float qt = FLT_MAX;
+    QTrav t;
+    t.cur = RT_DONE; t.sp = 1; t.best = 0; t.bu = 0; t.bv = 0; t.face = 0xFFFFFFFFu; t.tcull = 0; t.inv = mk(0, 0, 0); t.ood = mk(0, 0, 0);
+    for (;;) {
+        // the idle quads, lowest first, take the next needing lanes
+        const unsigned long long idle_q = __builtin_amdgcn_ballot_w64(!busy) & 0x1111111111111111ull;      // one bit per quad
+        const uint32_t n_idle = (uint32_t)__popcll(idle_q);
+        const uint32_t want = next + (uint32_t)__popcll(idle_q & ((1ull << (lane & 60u)) - 1ull));
+        const bool take = !busy && want < n;
+        const int src = (int)(take ? select_bit(m, want) : lane);
+        const float ox = __shfl(ray.o.x, src), oy = __shfl(ray.o.y, src), oz = __shfl(ray.o.z, src);
+        const float dx = __shfl(ray.d.x, src), dy = __shfl(ray.d.y, src), dz = __shfl(ray.d.z, src);
+        const float st = ANY ? __shfl(tmax, src) : FLT_MAX;
+        if (take) {
+            qr.o = mk(ox, oy, oz); qr.d = mk(dx, dy, dz); qt = st;
+            owner = (uint32_t)src;
+            busy = true;
+            quad_begin<ANY>(t, root, true, qr, qt, qs);
+        }
+        next = next + n_idle < n ? next + n_idle : n;
+        if (__builtin_amdgcn_ballot_w64(busy) == 0) break;                             // every ray served
+        const uint32_t keep = (S.debug >> 16) ? ((S.debug >> 16) & 31u) : RT_SERVE_KEEP;      // (experiments: RT_DEBUG_SKIP = keep << 16)
+        quad_run<ANY, COUNT>(S, t, qr, qt, qs, next < n ? keep * 4u : 0u, wk);
+        if (busy && t.cur == RT_DONE) {
+            QuadHit q;
+            quad_result<ANY>(t, q);
+            if (j == 0) {
+                uint32_t* box = mail + owner * 4u;
+                box[0] = q.face; box[1] = __float_as_uint(q.t); box[2] = __float_as_uint(q.u); box[3] = __float_as_uint(q.v);
+            }
+            busy = false;
+        }
+    }
+    if (need) {      // (LDS operations of one wave complete in order: the mailbox holds the quad's words)
+        const uint32_t* box = mail + lane * 4u;
+        out.face = box[0];
+        if (!ANY) { out.t = __uint_as_float(box[1]); out.u = __uint_as_float(box[2]); out.v = __uint_as_float(box[3]); }
     }
 }
 
@@ -1076,7 +1148,7 @@ __global__ __launch_bounds__(RT_WIDE_BLOCK_MAX) __attribute__((amdgpu_waves_per_
 // (SRC 2: rt_trace_form's caller-supplied rays, for the parity tests)
 template <int SRC, bool COUNT>
 __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WPE_ES))) void k_extend_serve(DScene S, LevelArgs A) {
-    __shared__ uint32_t lds_stack[RT_QSTACK * 16];
+    __shared__ uint32_t lds_stack[RT_SERVE_LDS];
     extend_wide_body<SRC, COUNT, 2>(S, A, lds_stack);
 }
 
@@ -1285,7 +1357,7 @@ __global__ __launch_bounds__(RT_WIDE_BLOCK_MAX) __attribute__((amdgpu_waves_per_
 // the hits of levels >= 1, one per lane, shadow rays through meshes by quad service
 template <bool COUNT, bool GPOW>
 __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WPE_SS))) void k_shade_serve(DScene S, LevelArgs A) {
-    __shared__ uint32_t lds_stack[RT_QSTACK * 16];
+    __shared__ uint32_t lds_stack[RT_SERVE_LDS];
     shade_wide_body<COUNT, GPOW, 2>(S, A, lds_stack);
 }
 
@@ -1701,7 +1773,7 @@ template <int PACKET>
 __global__ __launch_bounds__(RT_BLOCK) void k_intersect_lane(DScene S, int object, const float* __restrict__ rays, uint32_t n,
                                                              int32_t* __restrict__ hit_obj, float* __restrict__ dist_out,
                                                              float* __restrict__ normal_out) {
-    __shared__ uint32_t lds_stack[RT_QSTACK * 16];
+    __shared__ uint32_t lds_stack[RT_SERVE_LDS];
     const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
     const bool alive = i < n;
     Ray ray;
@@ -1748,7 +1820,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_intersect_lane(DScene S, int objec
 template <int PACKET>
 __global__ __launch_bounds__(RT_BLOCK) void k_occluded_lane(DScene S, const float* __restrict__ rays, const float* __restrict__ max_dist,
                                                             uint32_t n, uint8_t* __restrict__ occ) {
-    __shared__ uint32_t lds_stack[RT_QSTACK * 16];
+    __shared__ uint32_t lds_stack[RT_SERVE_LDS];
     const uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x;
     const bool alive = i < n;
     Ray ray;

@@ -530,6 +530,10 @@ class DeviceScene:
                                                         fptr(rgb), C.byref(st)))
         return rgb, st
 
+    def pass_samples(self):
+        """rt_scene_pass_samples: level-0 samples per pass (frames with more are rendered in several passes)."""
+        return int(self.lib.rt_scene_pass_samples(self.h))
+
     def set_pass_samples(self, samples):
         """rt_scene_set_pass_samples: level-0 samples per pass (power of two in [2^12, 2^26]; 0 = default)."""
         cabi.check(self.lib, self.lib.rt_scene_set_pass_samples(self.h, int(samples)))

@@ -150,7 +150,7 @@ def test_full_size_properties(workload):
     W, H = cam.imWidth, cam.imHeight
     assert st.level_rays[0] == W * H * p.spp and st.trace_calls == sum(st.level_rays)
     assert st.shadow_rays % len(fs.lights) == 0 and st.shadow_rays <= len(fs.lights) * st.trace_calls
-    assert st.passes == -(-(W * H) // max(64, (1 << 23) // p.spp)) and st.retries == 0
+    assert st.passes == -(-(W * H) // max(64, dev.pass_samples() // p.spp)) and st.retries == 0
     if not any(m.reflective or m.refractive for m in fs.materials):
         assert st.trace_calls == st.level_rays[0]                       # "shadows only": nothing bounces
     parts = np.zeros_like(a)
