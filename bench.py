@@ -64,6 +64,8 @@ def parse_args():
     ap.add_argument("--frames-per-batch", type=int, default=32,
                     help="frames (steps) rendered per library call, rt_render_batch_device: every launch then carries "
                          "that many frames' rays (1..32; 1 = one call per frame)")
+    ap.add_argument("--batch-samples", type=int, default=64 << 20,
+                    help="a batch holds at most this many level-0 samples (frames x pixels x samples per pixel, per rank)")
     ap.add_argument("--same-camera", action="store_true", help="experiments: every frame of a batch from the reference camera")
     ap.add_argument("--bvh", default="host", choices=("host", "device"),
                     help="BVH builder: the host's SAH tree (default) or the GPU's linear BVH (RT_SCENE_BVH_DEVICE)")
@@ -232,13 +234,15 @@ def main():
     # launch rate. So (1) the steps are rendered B frames per library call (rt_render_batch_device: the frames' rays share
     # every launch) and (2) two calls are in flight, each with its own scene workspace, stream and framebuffers. Every
     # frame is still rendered completely and compared with its camera's census frame below.
-    # ... as many as fill about one 8 M-sample pass of this rank (a batch of large frames would only add passes)
+    # ... as many as fill one pass of this rank (--batch-samples: 2^26 level-0 samples, the scenes' default pass on an
+    # MI355X; bunny_1080p per frame: 4 per call 0.287 ms, 8: 0.274, 16: 0.267, 32: 0.258 - tools/exp_batchsize.sh; a batch of
+    # large frames would only add passes)
     # a frame of several 8 M-sample passes fills the chip by itself: a second call in flight only competes for the caches
     # (4K 16 spp glass scene: 55 ms one call at a time, 67 ms with two)
     in_flight = args.frames_in_flight or (1 if (W * H * params.spp) // world >= 2 * (8 << 20) else 2)
     # ... and at least two calls per slot inside the timed region, so that the exchange of one call (gather, untile)
     # overlaps the rendering of the next whatever --steps is
-    B = max(1, min(32, args.frames_per_batch, (8 << 20) // max(1, (W * H * params.spp) // world), args.steps // (2 * in_flight)))
+    B = max(1, min(32, args.frames_per_batch, args.batch_samples // max(1, (W * H * params.spp) // world), args.steps // (2 * in_flight)))
     # the frames of a batch are DIFFERENT pictures: camera k on a small circle through the reference camera (camera 0)
     cams = [cam] * B if args.same_camera else wl.orbit_cameras(W, H, B)
     frame_bytes = H * W * 3

@@ -42,8 +42,15 @@ def orc():
         lib.orc_cast_rays.argtypes = [C.POINTER(rt_camera), C.POINTER(rt_params), C.POINTER(u32), u32, FP]
         lib.orc_intersect.argtypes = [C.POINTER(rt_flat_scene), C.c_int, FP, u32, C.POINTER(C.c_int32), FP, FP]
         lib.orc_occluded.argtypes = [C.POINTER(rt_flat_scene), FP, FP, u32, C.POINTER(C.c_uint8)]
+        lib.orc_stale_reads.argtypes = [C.c_int]
+        lib.orc_stale_reads.restype = C.c_ulonglong
         _orc = lib
     return _orc
+
+
+def stale_reads(reset=False):
+    """Times Sphere::intersect left `dist` as the caller had it (rt_oracle.c: orc_stale_reads) since the last reset."""
+    return int(orc().orc_stale_reads(1 if reset else 0))
 
 
 def have_ref():

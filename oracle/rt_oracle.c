@@ -57,6 +57,18 @@ static inline float fmin_std(float a, float b) { return (b < a) ? b : a; }
 /* container.h:255 */
 static inline v3 ray_point(const ray_t* r, float dist) { return vadd(r->o, vmul(r->d, dist)); }
 
+/* How often Sphere::intersect returned with `dist` as the caller left it (a root exactly 0, or NaN input), since the
+ * last orc_stale_reads(1). That is the ONLY place where the value a previous intersect() left in trace()'s tmpdist can
+ * reach a result - the reference's uninitialised read, and the HIP path's one stated deviation (a mesh that occludes a
+ * shadow ray leaves tmpdist as it was instead of at the mesh's closest t) - so a frame rendered with a count of 0
+ * cannot depend on either (tests/test_oracle_golden.py::test_stale_dist_branch_is_never_taken_by_the_parity_scenes). */
+static unsigned long long orc_stale_count = 0;
+unsigned long long orc_stale_reads(int reset) {
+    const unsigned long long n = orc_stale_count;
+    if (reset) orc_stale_count = 0;
+    return n;
+}
+
 /* ---- Sphere::intersect, primitives.cpp:173-196; getNormal :198-203 ---- */
 static int sphere_intersect(const rt_sphere* s, const ray_t* ray, float* dist, v3* normal) {
     const v3 c = vld(s->center);
@@ -72,7 +84,12 @@ static int sphere_intersect(const rt_sphere* s, const ray_t* ray, float* dist, v
         *dist = fmax_std(dist1, dist2);
     } else if (dist1 > 0 && dist2 > 0) {
         *dist = fmin_std(dist1, dist2);
-    } /* else: dist keeps the caller's value (see header) */
+    } else { /* dist keeps the caller's value (see header) */
+#ifdef _OPENMP
+#pragma omp atomic
+#endif
+        orc_stale_count++;
+    }
     v3 n = vsub(ray_point(ray, *dist), c);
     const float inv = (float)(1.0 / (double)s->radius); /* container.h:72-75: double reciprocal */
     *normal = vmul(n, inv);

@@ -242,6 +242,7 @@ def test_batch_equals_single_frames():
     assert not np.array_equal(singles[0], singles[4])
     stride = W * H * 3 + 256
     buf = torch.zeros((5 * stride,), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
     st = rt_stats()
     dev.render_batch_device(cams, p, buf.data_ptr(), stride, stats=st)
     got = buf.cpu().numpy()
@@ -250,6 +251,7 @@ def test_batch_equals_single_frames():
     assert st.trace_calls + st.shadow_rays == rays
     # asynchronous form, a rectangle of every frame
     buf.zero_()
+    torch.cuda.synchronize()       # torch's fill is not ordered against the scene's own stream
     rect = (40, 16, 200, 120)
     dev.render_batch_device(cams, p, buf.data_ptr(), stride, rect=rect)
     dev.status()
@@ -267,6 +269,7 @@ def test_batch_equals_single_frames():
         n = dev.lib.rt_tiles_owned(W, H, tw, th, part, 3)
         tstride = n * tw * th * 3
         t = torch.zeros((5 * tstride,), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
         dev.render_tiles_batch_device(cams, p, (tw, th), part, 3, t.data_ptr(), tstride)
         dev.status()
         parts.append(t.cpu().numpy().reshape(5, tstride))

@@ -338,6 +338,24 @@ def test_traversal_forms_agree(spp_grid):
     assert np.array_equal(default_img, base[0]) and st.trace_calls == base[1]
 
 
+def test_sphere_roots_exactly_zero(oracle_mod):
+    """Sphere::intersect with both roots exactly 0 (reference src/primitives.cpp:188-192 takes neither branch and `dist`
+    keeps the caller's value, defined as 0 at its first use here and in the oracle): a miss on the sphere, the plane
+    behind it is found, in every traversal form's kernels; the oracle's counter shows the branch was the one taken."""
+    from test_oracle_golden import tangent_scene_and_rays
+    fs, rays = tangent_scene_and_rays()
+    oracle_mod.stale_reads(reset=True)
+    h2, d2, n2 = oracle_mod.Oracle(fs).intersect(rays, -1)
+    assert oracle_mod.stale_reads(reset=True) == len(rays)
+    dev = DeviceScene(fs)
+    for form in (0, 1, 2):
+        h1, d1, n1 = dev.intersect(rays, -1, form=form)
+        assert np.array_equal(h1, h2)
+        hit = h2 >= 0
+        assert np.array_equal(d1[hit].view(np.uint32), d2[hit].view(np.uint32))
+    assert (dev.intersect(rays, 0)[0] == -1).all()
+
+
 def test_nan_normal_red_exit(oracle_mod):
     """trace()'s `return red` exit (reference src/raytracer.cpp:330-332): a reflective mesh whose vertex normals are NaN
     (what calcNormal gives for a degenerate face). The HIP path appends the reflection ray before the light loop has
@@ -412,6 +430,7 @@ def test_async_overflow_is_reported_then_fits():
     want, _ = DeviceScene(fs).render(cam, p)
     dev = DeviceScene(fs)
     frame = torch.zeros((72, 96, 3), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()       # torch's fill is not ordered against the scene's own stream
     ok = False
     for attempt in range(12):
         dev.render_device(cam, p, frame.data_ptr())
