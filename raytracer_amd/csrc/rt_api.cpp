@@ -772,6 +772,9 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
                     if ((rc = timed_launch(J, sa, RT_K_EXTEND_QUAD, [&] { launch_extend(src, RT_FORM_QUAD_RESUME, s->count_work, s->d, B, lv == 0 ? grid0q : 4u * RT_LEVEL_GRID, sa); })) != RT_OK) return rc;
                     if (overlap) HIP_TRY(record(2 * lv + 1));
                 }
+                // (Level 0's light loops fill the chip and run next to the closest-hit launches of levels 1, 2, ...; issuing
+                // them behind the extend launch of level 1 / 2 / 3 instead, so that the chain's first large levels have the
+                // chip to themselves, was measured slower: one frame at a time 0.686 -> 0.706 / 0.72 / 0.745 ms.)
                 const int ev_w = 2 * lv;
                 if ((rc = shade(RT_FORM_WIDE, lv, lv, ev_w)) != RT_OK) return rc;
                 if (quads) {
