@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "librt_amd.so")
+# RT_AMD_LIB: another build of the library (A/B experiments: tools/exp_ab_builds.sh); unset = the in-tree build
+LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(HERE, "csrc", "librt_amd.so")
 
 RT_SCENE_BVH_DEVICE = 1
 RT_SCENE_NO_PACKETS = 2

@@ -408,6 +408,12 @@ __device__ __forceinline__ void packet_traverse(const DScene& S, uint32_t root, 
             // 0.301 -> 0.310 ms per frame, with one instantiation of the box tests per octant 0.327: an SALU instruction costs
             // a SIMD about as much issue time as a VALU min/max - one scalar unit serves the CU's four SIMDs,
             // tools/valu_rate.hip - and both forms pushed more scalars into spill lanes.)
+            // (Also measured and not kept: leaves worked off ACROSS the lanes. A leaf is reached by few of the packet's rays,
+            // yet every lane tests its four triangles; with the mask of the lanes that hit each box kept beside the stack
+            // entries, a leaf reached by <= 16 rays was tested in one go - quad q pulls the q-th ray, lane j tests triangle
+            // j, the owner pulls the result back. Same bytes; the masks' bookkeeping (two more lane stacks, the sort's
+            // payload) cost 8-14 % of the level-0 kernels and the cheaper leaves won back only part of it: bunny_1080p
+            // 0.257 -> 0.299 ms per frame, 10 M-triangle field at 1080p 4.57 -> 4.83; tools/exp_ab_builds.sh.)
             // sort the four (key, ref) pairs, all wave-uniform: 5 compare-exchanges
 #define RT_CSWAP(i, j) { const bool sw = key[j] < key[i]; const uint32_t k0_ = sw ? key[j] : key[i], k1_ = sw ? key[i] : key[j]; \
                          const uint32_t r0_ = sw ? ref[j] : ref[i], r1_ = sw ? ref[i] : ref[j]; key[i] = k0_; key[j] = k1_; ref[i] = r0_; ref[j] = r1_; }
