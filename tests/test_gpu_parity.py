@@ -356,6 +356,37 @@ def test_sphere_roots_exactly_zero(oracle_mod):
     assert (dev.intersect(rays, 0)[0] == -1).all()
 
 
+def test_scanned_like_ply_frames(oracle_mod, tmp_path):
+    """A .ply with what scanned meshes bring - zero-area faces (NaN normals: trace()'s red exit where a ray hits next to
+    them), an unused vertex, a face listed in both orientations - loaded by the host surface, as a reflective mesh in
+    the scene.yaml setting: frame and ray counts against the oracle, closest hits bit for bit in every traversal form."""
+    from test_oracle_vs_ref import scanned_like_mesh
+    from raytracer_amd.scene import FlatScene, Mesh, material
+    mesh = Mesh.load_ply(scanned_like_mesh(tmp_path), rotation=(0, 0.5236, 0), scale=1.6, translation=(-0.5, -0.3, -5.5))
+    assert np.isnan(np.stack(mesh.v[3:])).any()
+    fs = FlatScene()
+    fs.add_sphere((1.2, 0.4, -4.0), 0.5, material((0.9, 0.9, 0.9), reflective=True, kr=0.8))
+    fs.add_mesh(mesh, material((0.8, 0.7, 0.6), reflective=True, kr=0.4))
+    fs.add_plane((0, 1, 0), 2.0, material((0.5, 0.5, 0.9), reflective=True, kr=0.3))
+    wl.add_yaml_lights(fs)
+    orc = oracle_mod.Oracle(fs)
+    dev = DeviceScene(fs)
+    cam, p = reference_camera(200, 150), Params(max_depth=5)
+    got, st1 = dev.render(cam, p)
+    want, st2 = orc.render(cam, p)
+    within1, equal, worst = frame_stats(got, want)
+    assert (st1.trace_calls, st1.shadow_rays) == (st2.trace_calls, st2.shadow_rays)
+    assert within1 >= 0.999, (within1, equal, worst)
+    rays = np.concatenate([camera_rays(oracle_mod, cam, Params(), 1), edge_rays(fs, 300, 3)])
+    h2, d2, n2 = orc.intersect(rays, -1)
+    hit = h2 >= 0
+    for form in (0, 1, 2):
+        h1, d1, n1 = dev.intersect(rays, -1, form=form)
+        assert np.array_equal(h1, h2)
+        assert np.array_equal(d1[hit].view(np.uint32), d2[hit].view(np.uint32))
+        assert np.array_equal(n1[hit].view(np.uint32), n2[hit].view(np.uint32))
+
+
 def test_nan_normal_red_exit(oracle_mod):
     """trace()'s `return red` exit (reference src/raytracer.cpp:330-332): a reflective mesh whose vertex normals are NaN
     (what calcNormal gives for a degenerate face). The HIP path appends the reflection ray before the light loop has

@@ -43,3 +43,33 @@ def test_random_rays(O):
     c1, _ = R.trace(Params(), rays[:4000])
     c2, _ = Q.trace(Params(), rays[:4000])
     assert same_bits(c1, c2)
+
+
+def scanned_like_mesh(tmp_path):
+    """What a scanned .ply brings that the procedural meshes do not: faces of zero area (a vertex named twice; three
+    vertices on a line; three identical points), a vertex no face uses, two faces with the same three vertices in
+    opposite orders. calcNormal divides by a zero length there, so their face normals - and the normals of the
+    vertices they touch - are NaN (reference src/primitives.cpp:238-362)."""
+    from raytracer_amd import meshgen
+    V, F = meshgen.blob(3, seed=5, radius=0.9)
+    V = np.concatenate([V, [[0.1, 0.2, 0.3], [0.2, 0.4, 0.6], [0.4, 0.8, 1.2], [5, 5, 5]]]).astype(np.float32)
+    n = V.shape[0] - 4
+    extra = [[0, 0, 1], [n, n + 1, n + 2], [7, 7, 7], [F[3][0], F[3][2], F[3][1]], [2, n, 9]]
+    F = np.concatenate([F, np.array(extra, F.dtype)])
+    path = tmp_path / "scanned.ply"
+    meshgen.write_ply(path, V, F)
+    return path
+
+
+def test_ply_loader_on_degenerate_faces(O, tmp_path):
+    """The host surface's loader against the reference's own Model::load_ply on such a file, bit for bit (NaNs by their
+    bits too), raw and through the scene loader's transform chain."""
+    from raytracer_amd.scene import Mesh
+    path = scanned_like_mesh(tmp_path)
+    for kw in (dict(transform=False), dict(rotation=(0.1, 0.5236, -0.2), scale=2.5, translation=(-1.5, -1, -6))):
+        mine = Mesh.load_ply(path, **kw)
+        arrs, bb = O.ref_load_ply(path, **kw)
+        assert np.isnan(np.stack(arrs[3:])).any()                       # the file does produce NaN normals
+        for a, b in zip(mine.v, arrs):
+            assert same_bits(a, b)
+        assert same_bits(mine.bb, bb)
