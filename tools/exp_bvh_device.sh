@@ -4,7 +4,7 @@ set -e
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 for w in ${WORKLOADS:-bunny_1080p c5_field_10m_1080p_4spp}; do for b in host device; do
-  timeout -k 10 300 python -u bench.py --workload $w --bvh $b --no-cpu-baseline --steps 10 --warmup 3 --watchdog 280 > gpurun_out/bd_${b}_$w.json 2> gpurun_out/bd_${b}_$w.err
+  timeout -k 10 300 python -u bench.py --workload $w --bvh $b --no-cpu-baseline --steps ${STEPS:-64} --warmup 16 --no-extras --watchdog 280 > gpurun_out/bd_${b}_$w.json 2> gpurun_out/bd_${b}_$w.err
   python - $b $w <<'PY'
 import json,sys; d=json.loads(open('gpurun_out/bd_%s_%s.json'%(sys.argv[1],sys.argv[2])).read().strip().splitlines()[-1])
 c=d['config']
