@@ -240,9 +240,9 @@ def main():
     # a frame of several 8 M-sample passes fills the chip by itself: a second call in flight only competes for the caches
     # (4K 16 spp glass scene: 55 ms one call at a time, 67 ms with two)
     in_flight = args.frames_in_flight or (1 if (W * H * params.spp) // world >= 2 * (8 << 20) else 2)
-    # ... and at least two calls per slot inside the timed region, so that the exchange of one call (gather, untile)
-    # overlaps the rendering of the next whatever --steps is
-    B = max(1, min(32, args.frames_per_batch, args.batch_samples // max(1, (W * H * params.spp) // world), args.steps // (2 * in_flight)))
+    # ... and at least one call per slot inside the timed region, so that the calls in flight overlap (and, with several
+    # ranks, the exchange of one call - gather, untile - the rendering of the other) whatever --steps is
+    B = max(1, min(32, args.frames_per_batch, args.batch_samples // max(1, (W * H * params.spp) // world), args.steps // in_flight))
     # the frames of a batch are DIFFERENT pictures: camera k on a small circle through the reference camera (camera 0)
     cams = [cam] * B if args.same_camera else wl.orbit_cameras(W, H, B)
     frame_bytes = H * W * 3
