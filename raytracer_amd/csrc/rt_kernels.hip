@@ -189,14 +189,17 @@ __device__ __forceinline__ float slab(float lox, float loy, float loz, float hix
     const float tz0 = __builtin_fmaf(loz, inv.z, -ood.z), tz1 = __builtin_fmaf(hiz, inv.z, -ood.z);
     const float tn = fmaxf(fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fminf(tz0, tz1)), 0.0f);
     float tf = fminf(fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fmaxf(tz0, tz1)), tmax);
-    tf *= 1.0000005f;   // conservative far bound (robust slab test)
+    tf *= 1.000001f;    // conservative far bound (robust slab test): 8 ulp, see safe_rcp
     hit = tn <= tf;
     return tn;
 }
 
+// (v_rcp_f32, 1 ulp, instead of the 11-instruction IEEE division: the reciprocal only scales an axis' plane distances
+// by (1 + e), |e| <= 2^-23, the same for both planes of the axis; slab()'s far bound is widened by 8 ulp, which covers
+// one ulp here and the half ulp of each FMA on either side of the comparison several times over. |a| >= 1e-30: no denormal in or out.)
 __device__ __forceinline__ float safe_rcp(float d) {
     const float a = fabsf(d) < 1e-30f ? copysignf(1e-30f, d) : d;   // NaN stays NaN: its axis then never culls
-    return 1.0f / a;
+    return __builtin_amdgcn_rcpf(a);
 }
 
 #define RT_DONE 0xFFFFFFFFu   // stack sentinel; has the leaf bit set, so the descent loop stops on it too
@@ -367,6 +370,14 @@ __device__ __forceinline__ int write_lane(int v, uint32_t value, uint32_t lane) 
     asm("v_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(sv), "{m0}"(sl));      // (one SGPR per VALU instruction: the lane goes through M0)
     return v;
 }
+// 1 if key != 0xFFFFFFFF else 0, on the scalar unit. (Opaque to the compiler on purpose: written as `key != ~0u ? 1 : 0`
+// the count goes through SCC, the stack pointer's whole chain is moved to the vector unit - v_cndmask, v_addc,
+// v_readfirstlane back for every push - and the node step grows by 13 vector instructions.)
+__device__ __forceinline__ uint32_t s_is_valid(uint32_t key) {
+    uint32_t r;
+    asm("s_not_b32 %0, %1\n\ts_min_u32 %0, %0, 1" : "=s"(r) : "s"(key) : "scc");
+    return r;
+}
 template <bool ANY, bool COUNT>
 __device__ __forceinline__ void packet_traverse(const DScene& S, uint32_t root, bool have, const Ray& ray, float tmax,
                                                 QuadHit& out, Work& wk) {
@@ -423,9 +434,9 @@ __device__ __forceinline__ void packet_traverse(const DScene& S, uint32_t root, 
             // (one v_writelane per entry, written whether the child was hit or not: an entry that was not hit lands above the
             // top of the stack - sp <= 63, the builders bound the traversal stack by RT_QSTACK - 1 pending entries - and is
             // overwritten by the next push)
-            stack = write_lane(stack, ref[3], sp); sp += key[3] != 0xFFFFFFFFu ? 1u : 0u;
-            stack = write_lane(stack, ref[2], sp); sp += key[2] != 0xFFFFFFFFu ? 1u : 0u;
-            stack = write_lane(stack, ref[1], sp); sp += key[1] != 0xFFFFFFFFu ? 1u : 0u;
+            stack = write_lane(stack, ref[3], sp); sp += s_is_valid(key[3]);
+            stack = write_lane(stack, ref[2], sp); sp += s_is_valid(key[2]);
+            stack = write_lane(stack, ref[1], sp); sp += s_is_valid(key[1]);
             if (key[0] != 0xFFFFFFFFu) cur = ref[0];
             else if (sp) { --sp; cur = (uint32_t)__builtin_amdgcn_readlane(stack, (int)sp); }
             else cur = RT_DONE;
