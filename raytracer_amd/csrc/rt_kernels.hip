@@ -1125,9 +1125,28 @@ __device__ __forceinline__ void locate(const Groups& G, uint32_t grp, uint32_t& 
     lim = f + lane_read(G.cnt, shard);
 }
 
+// The kernel's LevelArgs (second argument, after DScene) read again from the kernel-argument segment through a pointer
+// the compiler cannot see through. The packet kernels run at 7 waves per SIMD = 96 SGPRs, the packet loop needs most of
+// them (32 for a node, the sort, the masks), and what is used only AFTER the traversal - a dozen pointers of LevelArgs -
+// was kept across it in spill lanes: a v_writelane and a v_readlane each per 64 rays, on the pipe this path is short of.
+// Loaded again after the traversal they cost scalar loads instead.
+#ifndef RT_RELOAD_ARGS
+#define RT_RELOAD_ARGS 1
+#endif
+__device__ __forceinline__ LevelArgs reload_level_args() {
+#if __HIP_DEVICE_COMPILE__      // (the host pass of hipcc parses this too, and has no address spaces)
+    const RT_CONSTANT char* p = (const RT_CONSTANT char*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *(const RT_CONSTANT LevelArgs*)(p + ((sizeof(DScene) + alignof(LevelArgs) - 1) / alignof(LevelArgs)) * alignof(LevelArgs));
+#else
+    return LevelArgs{};
+#endif
+}
+
 // k_extend_wide: one ray per lane. Rays that never reach a mesh are finished here; the others are queued.
 template <int SRC, bool COUNT, int PACKET>
-__device__ __forceinline__ void extend_wide_body(const DScene& S, const LevelArgs& A, uint32_t* lds) {
+__device__ __forceinline__ void extend_wide_body(const DScene& S, const LevelArgs& A_, uint32_t* lds) {
+    const LevelArgs& A = A_;
     const bool level0 = SRC != 1;
     const ShardView v = shard_view(A, A.level, A.level);
     const Groups G = level0 ? make_groups_dense<false>(A.n0, A.chunk_log2) : make_groups<false>(v.start, v.cnt);
@@ -1146,11 +1165,18 @@ __device__ __forceinline__ void extend_wide_body(const DScene& S, const LevelArg
         const bool active = i < lim;
         Ray ray;
         ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 0);
-        const bool valid = active && fetch_ray<SRC>(A, 0, i, ray);
+        bool valid;
+        uint32_t dbg;
+        {   // (camera, pixel map, sample pattern: used once per group, before the traversal)
+            const LevelArgs Af = (RT_RELOAD_ARGS && PACKET == 1) ? reload_level_args() : A_;
+            valid = active && fetch_ray<SRC>(Af, 0, i, ray);
+            dbg = Af.debug;
+        }
         HitState h = fresh_hit();
         int susp = -1;
-        if (!(A.debug & 2u)) susp = closest_loop<false, COUNT, PACKET>(S, ray, valid, 0, h, lds, wk, SRC == 0);      // camera rays: neighbours
+        if (!(dbg & 2u)) susp = closest_loop<false, COUNT, PACKET>(S, ray, valid, 0, h, lds, wk, SRC == 0);      // camera rays: neighbours
         const bool parked = susp >= 0;
+        const LevelArgs A = (RT_RELOAD_ARGS && PACKET == 1) ? reload_level_args() : A_;
         ShardCounters* sc = A.sc + shard;
         uint32_t qslot = 0;
         if (!level0) qslot = wave_append(sc->qe + A.level, parked);
@@ -1274,7 +1300,7 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WPE
 // shadow loop (0/0, or where the per-lane kernel suspended). Writes node_a[i]; on suspension (QUAD = false) node_a[i]
 // holds {colour so far, tmpdist} and `parked` gets (li << 16) | k. Convergent.
 template <bool QUAD, bool COUNT, bool GPOW, int PACKET = 0>
-__device__ __forceinline__ void shade_ray(const DScene& S, const LevelArgs& A, uint32_t i, uint4 b, bool hit, bool writer,
+__device__ __forceinline__ void shade_ray(const DScene& S, const LevelArgs& A_, uint32_t i, uint4 b, bool hit, bool writer,
                                           V3 hitNormal, V3 hitPt, float rCoef, float tmpdist, uint32_t li0, uint32_t k0,
                                           bool resumed, V3 color, uint32_t* qs, Work& wk, uint32_t& n_shadow, int& parked, bool coherent = false) {
     // the material is fetched where it is used (after the shadow test) rather than held in registers across the
@@ -1283,6 +1309,7 @@ __device__ __forceinline__ void shade_ray(const DScene& S, const LevelArgs& A, u
     const float bias = 0.0001f;                                                          // raytracer.cpp:286
     bool red = false;
     parked = -1;
+    const uint32_t dbg = A_.debug;
     // the loop runs for the whole wave; `live` says whether this lane is still in ITS light loop
     for (uint32_t li = 0; li < S.n_lights; ++li) {                                       // raytracer.cpp:311-345
         const bool live = hit && !red && parked < 0 && li >= li0;
@@ -1295,7 +1322,7 @@ __device__ __forceinline__ void shade_ray(const DScene& S, const LevelArgs& A, u
         sr.d = lv;
         n_shadow += live && writer && !(resumed && li == li0);      // a resumed ray was counted when it was shot
         int sk;
-        const bool occ = occluded_loop<QUAD, COUNT, PACKET>(S, sr, live && !(A.debug & 1u), li == li0 ? k0 : 0u, ldist, tmpdist, sk, qs, wk, coherent);
+        const bool occ = occluded_loop<QUAD, COUNT, PACKET>(S, sr, live && !(dbg & 1u), li == li0 ? k0 : 0u, ldist, tmpdist, sk, qs, wk, coherent);
         if (live && sk >= 0) { parked = (int)((li << 16) | (uint32_t)sk); continue; }
         if (!live || occ) continue;
         if (isnan3(hitNormal)) { red = true; continue; }                                 // raytracer.cpp:330-332
@@ -1311,6 +1338,8 @@ __device__ __forceinline__ void shade_ray(const DScene& S, const LevelArgs& A, u
         color = color + mk((lc.x * mk4.y) * fs, (lc.y * mk4.y) * fs, (lc.z * mk4.y) * fs);
     }
     if (!hit || !writer) return;
+    // (packet kernels: what the stores below need is read again rather than kept in spill lanes across the light loop)
+    const LevelArgs A = (RT_RELOAD_ARGS && !QUAD && PACKET == 1) ? reload_level_args() : A_;
     if (parked >= 0) {
         A.node_a[i] = make_float4(color.x, color.y, color.z, tmpdist);
     } else if (red) {
@@ -1343,7 +1372,8 @@ __device__ __forceinline__ void flush_shadow(const LevelArgs& A, uint32_t n_shad
 // k_shade_wide: light loop, one hit per lane, for the hits of levels A.level..A.level_hi. Hits whose shadow rays never
 // reach a mesh are finished here; the others are queued (queue of A.level) at the point they stopped.
 template <bool COUNT, bool GPOW, int PACKET>
-__device__ __forceinline__ void shade_wide_body(const DScene& S, const LevelArgs& A, uint32_t* lds) {
+__device__ __forceinline__ void shade_wide_body(const DScene& S, const LevelArgs& A_, uint32_t* lds) {
+    const LevelArgs& A = A_;
     const bool level0 = A.level == 0;                 // then level_hi == 0: level 0 is not part of a range
     const ShardView v = shard_view(A, A.level, A.level_hi);
     const Groups G = level0 ? make_groups_dense<false>(A.n0, A.chunk_log2) : make_groups<false>(v.start, v.cnt);
@@ -1357,14 +1387,19 @@ __device__ __forceinline__ void shade_wide_body(const DScene& S, const LevelArgs
         locate(G, grp, shard, pos, lim);
         const uint32_t i = pos + (threadIdx.x & 63u);
         uint4 b = make_uint4(0, 0, 0, 0);
-        if (i < lim) b = A.node_b[i];
-        const bool hit = (b.w & (NODE_HIT | NODE_PARKED)) == NODE_HIT;
-        if (!__any(hit)) continue;                                                           // wave-uniform
         float4 hn = make_float4(0, 0, 0, 0), hp = make_float4(0, 0, 0, 0);
-        if (hit) { hn = A.hit_n[i]; hp = A.hit_p[i]; }
+        bool hit;
+        {
+            const LevelArgs Af = (RT_RELOAD_ARGS && PACKET == 1) ? reload_level_args() : A_;
+            if (i < lim) b = Af.node_b[i];
+            hit = (b.w & (NODE_HIT | NODE_PARKED)) == NODE_HIT;
+            if (!__any(hit)) continue;                                                       // wave-uniform
+            if (hit) { hn = Af.hit_n[i]; hp = Af.hit_p[i]; }
+        }
         int parked;
         shade_ray<false, COUNT, GPOW, PACKET>(S, A, i, b, hit, true, f4xyz(hn), f4xyz(hp), hp.w, hn.w, 0, 0, false, mk(0, 0, 0), lds, wk,
                                 n_shadow, parked, level0);      // the hits of camera rays: neighbours
+        const LevelArgs A = (RT_RELOAD_ARGS && PACKET == 1) ? reload_level_args() : A_;
         if (level0) {       // mark; hit_n.w (tmpdist at the start of the light loop) is not needed again: keep the resume point there
             if (parked >= 0) { A.node_b[i].w = b.w | NODE_SPARKED; A.hit_n[i].w = __uint_as_float((uint32_t)parked); }
         } else {
