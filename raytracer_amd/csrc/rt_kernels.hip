@@ -1131,8 +1131,9 @@ __device__ __forceinline__ void locate(const Groups& G, uint32_t grp, uint32_t& 
 // was kept across it in spill lanes: a v_writelane and a v_readlane each per 64 rays, on the pipe this path is short of.
 // Loaded again after the traversal they cost scalar loads instead.
 #ifndef RT_RELOAD_ARGS
-#define RT_RELOAD_ARGS 1
+#define RT_RELOAD_ARGS 2      // 0 never, 1 the packet kernels, 2 the quad-service kernels too
 #endif
+#define RT_RELOAD_FOR(PACKET) (RT_RELOAD_ARGS >= 2 ? (PACKET) != 0 : RT_RELOAD_ARGS == 1 && (PACKET) == 1)
 __device__ __forceinline__ LevelArgs reload_level_args() {
 #if __HIP_DEVICE_COMPILE__      // (the host pass of hipcc parses this too, and has no address spaces)
     const RT_CONSTANT char* p = (const RT_CONSTANT char*)__builtin_amdgcn_kernarg_segment_ptr();
@@ -1168,7 +1169,7 @@ __device__ __forceinline__ void extend_wide_body(const DScene& S, const LevelArg
         bool valid;
         uint32_t dbg;
         {   // (camera, pixel map, sample pattern: used once per group, before the traversal)
-            const LevelArgs Af = (RT_RELOAD_ARGS && PACKET == 1) ? reload_level_args() : A_;
+            const LevelArgs Af = (RT_RELOAD_FOR(PACKET)) ? reload_level_args() : A_;
             valid = active && fetch_ray<SRC>(Af, 0, i, ray);
             dbg = Af.debug;
         }
@@ -1176,7 +1177,7 @@ __device__ __forceinline__ void extend_wide_body(const DScene& S, const LevelArg
         int susp = -1;
         if (!(dbg & 2u)) susp = closest_loop<false, COUNT, PACKET>(S, ray, valid, 0, h, lds, wk, SRC == 0);      // camera rays: neighbours
         const bool parked = susp >= 0;
-        const LevelArgs A = (RT_RELOAD_ARGS && PACKET == 1) ? reload_level_args() : A_;
+        const LevelArgs A = (RT_RELOAD_FOR(PACKET)) ? reload_level_args() : A_;
         ShardCounters* sc = A.sc + shard;
         uint32_t qslot = 0;
         if (!level0) qslot = wave_append(sc->qe + A.level, parked);
@@ -1339,7 +1340,7 @@ __device__ __forceinline__ void shade_ray(const DScene& S, const LevelArgs& A_, 
     }
     if (!hit || !writer) return;
     // (packet kernels: what the stores below need is read again rather than kept in spill lanes across the light loop)
-    const LevelArgs A = (RT_RELOAD_ARGS && !QUAD && PACKET == 1) ? reload_level_args() : A_;
+    const LevelArgs A = (!QUAD && RT_RELOAD_FOR(PACKET)) ? reload_level_args() : A_;
     if (parked >= 0) {
         A.node_a[i] = make_float4(color.x, color.y, color.z, tmpdist);
     } else if (red) {
@@ -1390,7 +1391,7 @@ __device__ __forceinline__ void shade_wide_body(const DScene& S, const LevelArgs
         float4 hn = make_float4(0, 0, 0, 0), hp = make_float4(0, 0, 0, 0);
         bool hit;
         {
-            const LevelArgs Af = (RT_RELOAD_ARGS && PACKET == 1) ? reload_level_args() : A_;
+            const LevelArgs Af = (RT_RELOAD_FOR(PACKET)) ? reload_level_args() : A_;
             if (i < lim) b = Af.node_b[i];
             hit = (b.w & (NODE_HIT | NODE_PARKED)) == NODE_HIT;
             if (!__any(hit)) continue;                                                       // wave-uniform
@@ -1399,7 +1400,7 @@ __device__ __forceinline__ void shade_wide_body(const DScene& S, const LevelArgs
         int parked;
         shade_ray<false, COUNT, GPOW, PACKET>(S, A, i, b, hit, true, f4xyz(hn), f4xyz(hp), hp.w, hn.w, 0, 0, false, mk(0, 0, 0), lds, wk,
                                 n_shadow, parked, level0);      // the hits of camera rays: neighbours
-        const LevelArgs A = (RT_RELOAD_ARGS && PACKET == 1) ? reload_level_args() : A_;
+        const LevelArgs A = (RT_RELOAD_FOR(PACKET)) ? reload_level_args() : A_;
         if (level0) {       // mark; hit_n.w (tmpdist at the start of the light loop) is not needed again: keep the resume point there
             if (parked >= 0) { A.node_b[i].w = b.w | NODE_SPARKED; A.hit_n[i].w = __uint_as_float((uint32_t)parked); }
         } else {
