@@ -395,6 +395,14 @@ __device__ __forceinline__ uint32_t s_is_valid(uint32_t key) {
     asm("s_not_b32 %0, %1\n\ts_min_u32 %0, %0, 1" : "=s"(r) : "s"(key) : "scc");
     return r;
 }
+#ifndef RT_ANY_UNORDERED
+#define RT_ANY_UNORDERED 1
+#endif
+__device__ __forceinline__ uint32_t s_nonzero(uint32_t x) {      // x != 0 ? 1 : 0, likewise
+    uint32_t r;
+    asm("s_min_u32 %0, %1, 1" : "=s"(r) : "s"(__builtin_amdgcn_readfirstlane((int)x)) : "scc");
+    return r;
+}
 template <bool ANY, bool COUNT>
 __device__ __forceinline__ void packet_traverse(const DScene& S, uint32_t root, bool have, const Ray& ray, float tmax,
                                                 QuadHit& out, Work& wk) {
@@ -428,8 +436,20 @@ __device__ __forceinline__ void packet_traverse(const DScene& S, uint32_t root, 
                 unsigned long long m = __builtin_amdgcn_ballot_w64(h) & live_m;
                 if (ref[c] == RT_NO_CHILD) m = 0;
                 // distance of the first ray that hits the child (tn >= 0: its bits order like its value); none: last
+                if (ANY && RT_ANY_UNORDERED) { key[c] = s_nonzero((uint32_t)m | (uint32_t)(m >> 32)); continue; }      // (here: 1 = hit by some ray)
                 const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(tn), (__ffsll((long long)m) - 1) & 63);
                 key[c] = m ? first : 0xFFFFFFFFu;
+            }
+            if (ANY && RT_ANY_UNORDERED) {
+                // shadow rays: any occluder will do, so the children are visited in the order they lie in the node - no
+                // v_readlane of the distances, no sort (same answer: occluded or not does not depend on the order)
+                stack = write_lane(stack, ref[3], sp); sp += key[3];
+                stack = write_lane(stack, ref[2], sp); sp += key[2];
+                stack = write_lane(stack, ref[1], sp); sp += key[1];
+                if (key[0]) cur = ref[0];
+                else if (sp) { --sp; cur = (uint32_t)__builtin_amdgcn_readlane(stack, (int)sp); }
+                else cur = RT_DONE;
+                continue;
             }
             // (Measured and not kept: the packet walked once per direction OCTANT of its rays, so that the entering / leaving
             // plane of each axis is known and slab()'s six min/max per box fall away - with the planes picked by scalar selects
