@@ -396,15 +396,11 @@ __device__ __forceinline__ int write_lane(int v, uint32_t value, uint32_t lane) 
 }
 // 1 if key != 0xFFFFFFFF else 0, on the scalar unit. (Opaque to the compiler on purpose: written as `key != ~0u ? 1 : 0`
 // the count goes through SCC, the stack pointer's whole chain is moved to the vector unit - v_cndmask, v_addc,
-// v_readfirstlane back for every push - and the node step grows by 13 vector instructions.)
+// v_readfirstlane back for every push - and the node step grows by 13 vector instructions. The stack pointer itself
+// must not be an asm operand either: s_cmp + s_addc on it put it into a VGPR in the closest-hit kernels.)
 __device__ __forceinline__ uint32_t s_is_valid(uint32_t key) {
     uint32_t r;
     asm("s_not_b32 %0, %1\n\ts_min_u32 %0, %0, 1" : "=s"(r) : "s"(key) : "scc");
-    return r;
-}
-__device__ __forceinline__ uint32_t s_nonzero(uint32_t x) {      // x != 0 ? 1 : 0, likewise
-    uint32_t r;
-    asm("s_min_u32 %0, %1, 1" : "=s"(r) : "s"(__builtin_amdgcn_readfirstlane((int)x)) : "scc");
     return r;
 }
 template <bool ANY, bool COUNT>
@@ -437,12 +433,25 @@ __device__ __forceinline__ void packet_traverse(const DScene& S, uint32_t root, 
                 bool h;
                 const float tn = slab(a.x, a.y, a.z, b.x, b.y, b.z, inv, ood, cull, h);
                 // (the ballot of the comparison itself, masked by scalars: a ballot of `h && live && ...` goes through a VGPR)
-                unsigned long long m = __builtin_amdgcn_ballot_w64(h) & live_m;
-                if (ref[c] == RT_NO_CHILD) m = 0;
+                // The scalar side of a node step weighs as much as its vector side (the ANY form below, which drops the sort,
+                // made the level-0 shade launch 7 % faster), so the key of a child is four instructions written out: s_and_b64
+                // leaves "some ray hit" in SCC, which the compiler's own sequence (compare with zero, selects for the lane
+                // number and for the key: 8 scalar instructions) does not use. v_readlane takes the lane from bits 5:0 of
+                // its operand (s_ff1 of an empty mask is -1: lane 63, and the key becomes -1 anyway). No wait states needed:
+                // the lane select is written by the scalar unit, the select after it reads an SGPR like any other.
+                // (m = the rays that hit the child, none for an empty slot)
+                const unsigned long long hm = __builtin_amdgcn_ballot_w64(h);
+                unsigned long long m;
+                if (ANY && RT_ANY_UNORDERED) {       // 1 = hit by some ray
+                    asm("s_cmp_lg_u32 %4, -1\n\ts_cselect_b64 %0, %3, 0\n\ts_and_b64 %0, %2, %0\n\ts_cselect_b32 %1, 1, 0"
+                        : "=&s"(m), "=s"(key[c]) : "s"(hm), "s"(live_m), "s"(ref[c]) : "scc");
+                    continue;
+                }
                 // distance of the first ray that hits the child (tn >= 0: its bits order like its value); none: last
-                if (ANY && RT_ANY_UNORDERED) { key[c] = s_nonzero((uint32_t)m | (uint32_t)(m >> 32)); continue; }      // (here: 1 = hit by some ray)
-                const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(tn), (__ffsll((long long)m) - 1) & 63);
-                key[c] = m ? first : 0xFFFFFFFFu;
+                uint32_t first_lane;
+                asm("s_cmp_lg_u32 %6, -1\n\ts_cselect_b64 %0, %4, 0\n\ts_and_b64 %0, %3, %0\n\ts_ff1_i32_b64 %1, %0\n\t"
+                    "v_readlane_b32 %2, %5, %1\n\ts_cselect_b32 %2, %2, -1"
+                    : "=&s"(m), "=&s"(first_lane), "=&s"(key[c]) : "s"(hm), "s"(live_m), "v"(tn), "s"(ref[c]) : "scc");
             }
             if (ANY && RT_ANY_UNORDERED) {
                 // shadow rays: any occluder will do, so the children are visited in the order they lie in the node - no
@@ -467,8 +476,11 @@ __device__ __forceinline__ void packet_traverse(const DScene& S, uint32_t root, 
             // payload) cost 8-14 % of the level-0 kernels and the cheaper leaves won back only part of it: bunny_1080p
             // 0.257 -> 0.299 ms per frame, 10 M-triangle field at 1080p 4.57 -> 4.83; tools/exp_ab_builds.sh.)
             // sort the four (key, ref) pairs, all wave-uniform: 5 compare-exchanges
-#define RT_CSWAP(i, j) { const bool sw = key[j] < key[i]; const uint32_t k0_ = sw ? key[j] : key[i], k1_ = sw ? key[i] : key[j]; \
-                         const uint32_t r0_ = sw ? ref[j] : ref[i], r1_ = sw ? ref[i] : ref[j]; key[i] = k0_; key[j] = k1_; ref[i] = r0_; ref[j] = r1_; }
+            // (s_min_u32 leaves "the first operand is the minimum" in SCC: four instructions per compare-exchange, not five)
+#define RT_CSWAP(i, j) { uint32_t k0_, k1_, r0_, r1_; \
+                         asm("s_min_u32 %0, %4, %5\n\ts_cselect_b32 %2, %6, %7\n\ts_cselect_b32 %3, %7, %6\n\ts_max_u32 %1, %4, %5" \
+                             : "=&s"(k0_), "=&s"(k1_), "=&s"(r0_), "=&s"(r1_) : "s"(key[i]), "s"(key[j]), "s"(ref[i]), "s"(ref[j]) : "scc"); \
+                         key[i] = k0_; key[j] = k1_; ref[i] = r0_; ref[j] = r1_; }
             RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
 #undef RT_CSWAP
             // the farthest goes in first, the nearest is visited next
