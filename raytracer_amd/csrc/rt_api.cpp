@@ -548,10 +548,18 @@ static bool expect_large(const rt_scene* s, uint32_t pass, int lo, int hi) {
     // per level whatever their size (bunny_1080p 0.389 -> 0.362 ms, 10 M-triangle field at 1080p 6.04 -> 5.48 ms); where
     // the deeper levels use packets too (16+ spp) a level pays for the per-lane kernels from about a million rays on
     // (field at 8K 64 spp: threshold 131 k 829 ms, 1 M 727 ms, 4 M 818 ms; 4K glass scene flat up to 1 M, 73 ms at 4 M).
-    const char* e = std::getenv("RT_LARGE_THR");      // experiments and tests
-    const uint64_t thr = e ? uint64_t(std::atoll(e)) : s->d.packet >= 2 ? (1u << 20) : s->d.packet == 1 ? ~0ull : 16u * RT_LEVEL_GRID;
-    for (int l = lo; l <= hi; ++l)
+    // Packets pay while the 64 samples of a block still travel together, and that wears off with every bounce: level 1
+    // from a million rays on, level 2 from 8 M, deeper levels never (tools/exp_c5_pass.sh at 2^26-sample passes. The
+    // field at 8K 64 spp, every level from 1 M on: 520 ms; level 1 only: 468; levels 1 and 2 from 1 M: 525, level 2 from
+    // 8 M: 470; no packets below level 0: 603. The 4K glass scene, whose level 2 holds 9 M rays per pass: every level
+    // 29.7 ms, level 1 only 29.7, levels 1 and 2 28.9.)
+    const char* e = std::getenv("RT_LARGE_THR");      // experiments and tests: one threshold for the levels up to RT_LARGE_MAXLV
+    const char* em = std::getenv("RT_LARGE_MAXLV");
+    const int max_lv = em ? std::atoi(em) : (e || s->d.packet < 2) ? RT_MAX_LEVELS : 2;
+    for (int l = lo; l <= hi && l <= max_lv; ++l) {
+        const uint64_t thr = e ? uint64_t(std::atoll(e)) : s->d.packet >= 2 ? (l == 1 ? (1u << 20) : (8u << 20)) : s->d.packet == 1 ? ~0ull : 16u * RT_LEVEL_GRID;
         if (level_hint(s, pass, l) > thr) return true;
+    }
     return false;
 }
 
