@@ -627,6 +627,7 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
         LevelArgs A = J.base;
         A.n0 = cnt * spp;
         A.sample0 = (px0 + done) * spp;
+        A.fast32 = A.sample0 + A.n0 <= 0xFFFFFFFFull ? 1u : 0u;
         A.sc = pc->sc;
         A.cancelled = pc->cancel;
         A.host_overflow = s->h_overflow;
@@ -928,7 +929,10 @@ static int render_frame(rt_scene* s, const rt_camera* cam, uint32_t n_frames, co
     B.aa = s->d_aa;
     B.fp = s->d_fp;
     B.pm = pm;
+    rt_fill_recips(B.pm);
     B.frame_samples = n_frames > 1 ? uint32_t(frame_px * spp) : 0u;
+    B.frame_px = B.frame_samples / spp;
+    B.z_spp = rt_recip32(spp); B.z_frame_samples = rt_recip32(B.frame_samples); B.z_frame_px = rt_recip32(B.frame_px);
     B.out_stride = out_stride;
     for (int lv = 0; lv <= prm->max_depth; ++lv)
         if (expect_large(s, 0, lv, lv)) J.large_mask |= 1u << lv;      // (key of the opt-in graph cache only)

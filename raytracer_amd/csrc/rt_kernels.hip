@@ -826,17 +826,32 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 
 // Sample index -> pixel. Pixels are numbered so that 64 consecutive ones form an 8x8 block (bit-interleaved
 // inside the block): a wave's primary rays stay close together for the BVH.
+// n / d and the remainder with z = rt_recip32(d) (rt_launch.h): floor(n z / 2^32) is the quotient or one less.
+__device__ __forceinline__ uint32_t udivmod32(uint32_t n, uint32_t d, uint32_t z, uint32_t& r) {
+    uint32_t q = __umulhi(n, z);
+    r = n - q * d;
+    if (r >= d) { ++q; r -= d; }
+    return q;
+}
+// FAST: q fits 32 bits (LevelArgs::fast32, wave-uniform) - the same integers by reciprocal multiplication
+template <bool FAST>
 __device__ __forceinline__ bool map_pixel(const PixelMap& pm, uint64_t q, uint32_t& x, uint32_t& y, uint64_t& out_off, bool& in_buf) {
     const uint32_t per_tile = pm.tile_w * pm.tile_h;
-    const uint32_t j = (uint32_t)(q / per_tile);        // ordinal of the owned tile
-    const uint32_t r = (uint32_t)(q % per_tile);
     const uint32_t sub_x = pm.tile_w >> 3;               // 8x8 sub-blocks per tile row
+    uint32_t j, r;                                       // ordinal of the owned tile, pixel within it
+    if (FAST) j = udivmod32((uint32_t)q, per_tile, pm.z_per_tile, r);
+    else { j = (uint32_t)(q / per_tile); r = (uint32_t)(q % per_tile); }
     const uint32_t sb = r >> 6, w = r & 63u;
     const uint32_t mx = (w & 1u) | ((w >> 1) & 2u) | ((w >> 2) & 4u);
     const uint32_t my = ((w >> 1) & 1u) | ((w >> 2) & 2u) | ((w >> 3) & 4u);
-    const uint32_t lx = (sb % sub_x) * 8u + mx, ly = (sb / sub_x) * 8u + my;
+    uint32_t sbx, sby;
+    if (FAST) sby = udivmod32(sb, sub_x, pm.z_sub_x, sbx);
+    else { sbx = sb % sub_x; sby = sb / sub_x; }
+    const uint32_t lx = sbx * 8u + mx, ly = sby * 8u + my;
     const uint32_t T = pm.part + j * pm.n_parts;         // global tile id, row-major
-    const uint32_t tx = T % pm.tiles_x, ty = T / pm.tiles_x;
+    uint32_t tx, ty;
+    if (FAST) ty = udivmod32(T, pm.tiles_x, pm.z_tiles_x, tx);
+    else { tx = T % pm.tiles_x; ty = T / pm.tiles_x; }
     x = pm.x0 + tx * pm.tile_w + lx;
     y = pm.y0 + ty * pm.tile_h + ly;
     const bool valid = j < pm.n_owned && ty < pm.tiles_y && x < pm.x0 + pm.w && y < pm.y0 + pm.h;
@@ -963,14 +978,25 @@ __device__ __forceinline__ void flush_work(unsigned long long* work, uint32_t ke
 template <int SRC>
 __device__ __forceinline__ bool fetch_ray(const LevelArgs& A, uint32_t begin, uint32_t i, Ray& ray) {
     if (SRC == 0) {
-        uint64_t g = A.sample0 + (i - begin);
-        uint32_t frame = 0;
-        if (A.frame_samples) {      // batch: the frame is the same for the whole 64-entry block (frame_samples % 64 == 0)
-            frame = (uint32_t)__builtin_amdgcn_readfirstlane((int)((A.sample0 + ((i - begin) & ~63u)) / A.frame_samples));
-            g -= (uint64_t)frame * A.frame_samples;
+        uint32_t frame = 0, x, y, k;
+        uint64_t off; bool inb;
+        if (A.fast32) {             // (wave-uniform) every index of the pass fits 32 bits: divisions by reciprocal
+            uint32_t g = (uint32_t)A.sample0 + (i - begin), rem;
+            if (A.frame_samples) {  // batch: the frame is the same for the whole 64-entry block (frame_samples % 64 == 0)
+                frame = (uint32_t)__builtin_amdgcn_readfirstlane((int)udivmod32((uint32_t)A.sample0 + ((i - begin) & ~63u), A.frame_samples, A.z_frame_samples, rem));
+                g -= frame * A.frame_samples;
+            }
+            const uint32_t px = udivmod32(g, A.spp, A.z_spp, k);
+            if (!map_pixel<true>(A.pm, px, x, y, off, inb)) return false;
+        } else {
+            uint64_t g = A.sample0 + (i - begin);
+            if (A.frame_samples) {
+                frame = (uint32_t)__builtin_amdgcn_readfirstlane((int)((A.sample0 + ((i - begin) & ~63u)) / A.frame_samples));
+                g -= (uint64_t)frame * A.frame_samples;
+            }
+            if (!map_pixel<false>(A.pm, g / A.spp, x, y, off, inb)) return false;
+            k = (uint32_t)(g % A.spp);
         }
-        uint32_t x, y; uint64_t off; bool inb;
-        if (!map_pixel(A.pm, g / A.spp, x, y, off, inb)) return false;
         DCamera cam;                                                      // wave-uniform: scalar loads
         {
             const RT_CONSTANT uint32_t* src = (const RT_CONSTANT uint32_t*)(const void*)(&A.fp[frame].cam);
@@ -978,7 +1004,7 @@ __device__ __forceinline__ bool fetch_ray(const LevelArgs& A, uint32_t begin, ui
 #pragma unroll
             for (int k = 0; k < (int)(sizeof(DCamera) / 4); ++k) dst[k] = src[k];
         }
-        ray = cast_ray(cam, A.aa, x, y, (uint32_t)(g % A.spp));
+        ray = cast_ray(cam, A.aa, x, y, k);
     } else if (SRC == 1) {
         const float4 o = A.rays[2 * (size_t)(i - A.n0)], d = A.rays[2 * (size_t)(i - A.n0) + 1];
         ray.o = f4xyz(o); ray.d = f4xyz(d);
@@ -1754,14 +1780,24 @@ __global__ __launch_bounds__(256) void k_resolve(DScene S, LevelArgs A, uint8_t*
     }
     if (p >= npix) return;
     uint32_t x, y; uint64_t off; bool inb;
-    uint64_t q = A.sample0 / A.spp + p;
-    if (A.frame_samples) {          // batch: frame b's buffer starts b * out_stride bytes further
-        const uint32_t frame_px = A.frame_samples / A.spp;
-        const uint32_t b = (uint32_t)(q / frame_px);
-        q -= (uint64_t)b * frame_px;
-        out += (uint64_t)b * A.out_stride;
+    bool valid;
+    if (A.fast32) {
+        uint32_t rem, q = udivmod32((uint32_t)A.sample0, A.spp, A.z_spp, rem) + p;
+        if (A.frame_samples) {      // batch: frame b's buffer starts b * out_stride bytes further
+            const uint32_t b = udivmod32(q, A.frame_px, A.z_frame_px, q);
+            out += (uint64_t)b * A.out_stride;
+        }
+        valid = map_pixel<true>(A.pm, q, x, y, off, inb);
+    } else {
+        uint64_t q = A.sample0 / A.spp + p;
+        if (A.frame_samples) {
+            const uint32_t frame_px = A.frame_samples / A.spp;
+            const uint32_t b = (uint32_t)(q / frame_px);
+            q -= (uint64_t)b * frame_px;
+            out += (uint64_t)b * A.out_stride;
+        }
+        valid = map_pixel<false>(A.pm, q, x, y, off, inb);
     }
-    const bool valid = map_pixel(A.pm, q, x, y, off, inb);
     if (!valid) {
         if (A.pm.tiled_out && inb) { out[off] = 0; out[off + 1] = 0; out[off + 2] = 0; }
         return;

@@ -46,8 +46,17 @@ struct PixelMap {
     uint32_t n_owned;            // tiles this part owns
     uint32_t tiled_out;          // 1: tile-major output buffer, 0: row-major full image
     uint32_t stride_px;          // row-major: pixels per image row
-    uint32_t pad;
+    uint32_t z_per_tile, z_sub_x, z_tiles_x;   // rt_recip32 of tile_w*tile_h, tile_w/8, tiles_x (rt_fill_recips)
 };
+
+// floor(2^32 / d) (d = 1: 2^32 - 1): with it n / d for any 32-bit n is one multiply-high and one correction step
+// (rt_kernels.hip: udivmod32) instead of the ~20-instruction expansion of a 32-bit division or the ~100 (half of them
+// scalar) of a 64-bit one. The sample index -> frame, pixel, tile arithmetic at the top of every level-0 wave was five
+// such divisions, three of them 64-bit: a sixth of the level-0 closest-hit kernel's instructions.
+static inline uint32_t rt_recip32(uint32_t d) { return d <= 1u ? 0xFFFFFFFFu : uint32_t((1ull << 32) / d); }
+static inline void rt_fill_recips(PixelMap& pm) {
+    pm.z_per_tile = rt_recip32(pm.tile_w * pm.tile_h); pm.z_sub_x = rt_recip32(pm.tile_w >> 3); pm.z_tiles_x = rt_recip32(pm.tiles_x);
+}
 
 // Pool entry i = one trace() invocation ("node"). Entries [0, n0) are level 0 (sample order). The rest of the pool is
 // RT_SHARDS equal sub-pools; in each, level k >= 1 follows level k-1. An entry's shard is fixed for the whole tree:
@@ -111,7 +120,8 @@ struct LevelArgs {
     const float* user_rays;      // SRC 2
     const FrameParams* fp;       // [n_frames] camera + background of the frames (device); the background is the batch's
     uint32_t frame_samples;      // batch: level-0 samples per frame (a multiple of 64); 0 = one frame
-    uint32_t pad3;
+    uint32_t fast32;             // this pass' sample indices fit 32 bits (sample0 + n0 <= 2^32 - 1): the divisions below by reciprocal
+    uint32_t z_spp, z_frame_samples, frame_px, z_frame_px;   // rt_recip32 of spp, frame_samples, frame_samples / spp
     uint64_t out_stride;         // batch: bytes between the output buffers of consecutive frames
     uint32_t debug;              // timing experiments only (RT_DEBUG_SKIP)
     uint32_t chunk_log2;         // level-0 shard chunks (RT_SHARD_CHUNK_LOG2; RT_CHUNK_LOG2 in the environment for experiments)

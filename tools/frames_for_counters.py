@@ -1,6 +1,7 @@
 """Target program of tools/collect_counters.sh: renders, one call per frame on the scene's stream,
-    2 full frames (warm-up: the second knows its level sizes), 1 frame at max_depth 0, 1 full frame.
-A frame starts with one k_set_frame_params launch, so tools/counters_table.py finds frames 3 and 4 by counting those.
+    1 full frame, 1 frame at max_depth 0, 2 full frames (a frame is scheduled by the level sizes of the frame before it:
+    the first after the depth-0 frame sees empty bounce levels, the second is the steady state that is counted).
+A frame starts with one k_set_frame_params launch, so tools/counters_table.py finds frames 2 and 4 by counting those.
 At max_depth 0 a frame runs exactly its level-0 launches, one per kernel: their counters are PER LAUNCH."""
 import os
 import sys
@@ -17,6 +18,6 @@ p0 = Params(background=tuple(p.c.background), max_depth=0, aa=p.aa)
 dev = DeviceScene(fs)
 frame = torch.zeros((cam.imHeight, cam.imWidth, 3), dtype=torch.uint8, device="cuda")
 torch.cuda.synchronize()
-for prm in (p, p, p0, p):
+for prm in (p, p0, p, p):
     dev.render_device(cam, prm, frame.data_ptr())
     dev.status()
