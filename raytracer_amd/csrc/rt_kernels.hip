@@ -420,7 +420,7 @@ __device__ __forceinline__ void packet_traverse(const DScene& S, uint32_t root, 
     unsigned long long live_m = __builtin_amdgcn_ballot_w64(have);      // `live` as a scalar (ANY: shrinks at the leaves)
     uint32_t cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)(live_m ? root : RT_DONE));   // RT_NO_CHILD == RT_DONE
     while (cur != RT_DONE) {
-        if (!(cur & RT_LEAF_BIT)) {
+        while (!(cur & RT_LEAF_BIT)) {      // (RT_DONE has the leaf bit)
             const RT_CONSTANT u32x4* np = (const RT_CONSTANT u32x4*)(const void*)(S.nodes) + 8u * (size_t)cur;
             if (COUNT) { wk.nodes += live; wk.wave_nodes += wave_once(); }
             const float cull = ANY ? best : best * 1.000001f;
@@ -498,7 +498,9 @@ __device__ __forceinline__ void packet_traverse(const DScene& S, uint32_t root, 
             if (key[0] != 0xFFFFFFFFu) cur = ref[0];
             else if (sp) { --sp; cur = (uint32_t)__builtin_amdgcn_readlane(stack, (int)sp); }
             else cur = RT_DONE;
-        } else {
+        }
+        if (cur == RT_DONE) break;
+        {
             const uint32_t cnt = ((cur >> 27) & 15u) + 1u;
             const RT_CONSTANT u32x4* lp = (const RT_CONSTANT u32x4*)(const void*)(S.leaves) + 12u * (size_t)(cur & RT_LEAF_START_MASK);
             if (COUNT) { wk.tris += live ? cnt : 0u; wk.wave_tris += wave_once(); }
