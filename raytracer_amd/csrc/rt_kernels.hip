@@ -646,10 +646,12 @@ __device__ __forceinline__ int closest_loop(const DScene& S, const Ray& ray, boo
         if (ob.x == RT_OBJ_SPHERE) {
             if (COUNT) wk.spheres += go && counter;
             if (go && !(S.debug & 16u)) hit = sphere_isect(prm, __uint_as_float(ob.w), ray, h.tmpdist, tmpnormal, coherent);
-        } else if (ob.x == RT_OBJ_PLANE) {
+        }
+        if (ob.x == RT_OBJ_PLANE) {
             if (COUNT) wk.planes += go && counter;
             if (go && !(S.debug & 16u)) hit = plane_isect(prm, ray, h.tmpdist, tmpnormal);
-        } else {
+        }
+        if (ob.x != RT_OBJ_SPHERE && ob.x != RT_OBJ_PLANE) {      // (separate tests: see occluded_loop)
             // Model::intersect (reference src/primitives.cpp:364-384): dist = FLT_MAX, bounding-sphere gate, closest
             // face, normal = (1-u-v)*n0 + u*n1 + v*n2 (primitives.cpp:80, not normalised)
             const ModelRef m = load_model(S.models, ob.y);
@@ -710,19 +712,23 @@ __device__ __forceinline__ bool occluded_loop(const DScene& S, const Ray& ray, b
         const u32x4 ob_n = ldc4(S.objects, 2 * kn), pb_n = ldc4(S.objects, 2 * kn + 1);
         const float4 prm = as_f4(pb);
         const bool go = alive && k >= k0 && !in && susp < 0;
+        // (three separate tests of the wave-uniform type, not if / else if / else: the structurised chain carries flag
+        // registers and undefined values from one branch to the next)
         if (ob.x == RT_OBJ_SPHERE) {
             if (COUNT) wk.spheres += go && counter;
             if (go) {
                 const bool hit = sphere_isect(prm, __uint_as_float(ob.w), ray, tmpdist, tmpnormal, coherent);
                 in = hit && tmpdist < ldist;
             }
-        } else if (ob.x == RT_OBJ_PLANE) {
+        }
+        if (ob.x == RT_OBJ_PLANE) {
             if (COUNT) wk.planes += go && counter;
             if (go) {
                 const bool hit = plane_isect(prm, ray, tmpdist, tmpnormal);
                 in = hit && tmpdist < ldist;
             }
-        } else {
+        }
+        if (ob.x != RT_OBJ_SPHERE && ob.x != RT_OBJ_PLANE) {
             const ModelRef m = load_model(S.models, ob.y);
             bool need = go;
             if (m.bb.w >= 0) {
