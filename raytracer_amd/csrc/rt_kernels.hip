@@ -899,10 +899,13 @@ __device__ __forceinline__ bool map_pixel(const PixelMap& pm, uint64_t q, uint32
 #define RT_WPE_EW 7
 #endif
 #ifndef RT_WPE_ES
-#define RT_WPE_ES 5      // k_extend_serve (95 VGPRs, nothing spilled)
+#define RT_WPE_ES 7      // k_extend_serve: 72 VGPRs with a few values in scratch. Measured after the packet kernels' diet (5 / 6 / 7 / 8
+                         // with RT_WPE_SS 5): bunny_1080p 0.2346 / 0.2290 / 0.2271 / 0.2291 ms, field at 1080p 4.26 / 4.14 / 4.12 / 4.14,
+                         // at 8K 454 / 441 / 428 / 417, 4K glass scene 28.2 / 27.7 / 28.3 / 29.1 (its deep levels are latency-bound and
+                         // pay for the spills)
 #endif
 #ifndef RT_WPE_SS
-#define RT_WPE_SS 4      // k_shade_serve (5: 96 VGPRs with 11 spilled)
+#define RT_WPE_SS 5      // k_shade_serve: 96 VGPRs with 11 spilled (4 -> 5: bunny_1080p -1 %, field -1 %; 6: 4K glass scene +2.5 %)
 #endif
 #ifndef RT_WPE_PK
 #define RT_WPE_PK 7      // the per-lane kernels when they carry the packet traversal (5/6: bunny_1080p 0.292 ms, 7: 0.281, 8: 0.301; 4K glass scene 43.8 / 42.4 / 43.5)
