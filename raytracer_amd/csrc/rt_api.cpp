@@ -627,7 +627,7 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
         LevelArgs A = J.base;
         A.n0 = cnt * spp;
         A.sample0 = (px0 + done) * spp;
-        A.fast32 = A.sample0 + A.n0 <= 0xFFFFFFFFull ? 1u : 0u;
+        A.fast32 = (A.sample0 + A.n0 <= 0xFFFFFFFFull && !std::getenv("RT_NO_FAST32")) ? 1u : 0u;      // (the variable: tests of the 64-bit path)
         A.sc = pc->sc;
         A.cancelled = pc->cancel;
         A.host_overflow = s->h_overflow;

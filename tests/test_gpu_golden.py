@@ -85,6 +85,52 @@ def test_tiles_on_one_gpu_equal_the_full_frame():
         assert np.array_equal(tiling.untile([a.cpu().numpy() for a in allt], W, H, tw, th), full)
 
 
+def test_index_arithmetic_paths_agree():
+    """Sample index -> frame / pixel / tile: where a pass' indices fit 32 bits the kernels divide by reciprocal
+    multiplication (udivmod32), else by the 64-bit expansion (frames beyond 2^32 samples, too large to test).
+    RT_NO_FAST32 forces the latter: full frame at 3 samples per pixel (a divisor that is not a power of two), a
+    rectangle, tiles in 3 parts and a batch of 3 frames give the same bytes both ways."""
+    import os
+    import torch
+    fs = wl.scene_bunny(10, third="glass2")
+    cam = reference_camera(400, 296)
+    from raytracer_amd.scene import make_camera
+    cams = [cam] + [make_camera(400, 296, eye=(0.3 * k, 0.1 * k, 0.2 * k), at=(0.05 * k, 0, -1)) for k in (1, 2)]
+    p = Params(max_depth=3, aa=((0.5, 0.5), (0.25, 0.75)))
+    W, H = cam.imWidth, cam.imHeight
+    got = {}
+    saved = os.environ.get("RT_NO_FAST32")
+    try:
+        for mode in ("fast", "wide"):
+            if mode == "wide":
+                os.environ["RT_NO_FAST32"] = "1"            # read at every pass
+            else:
+                os.environ.pop("RT_NO_FAST32", None)
+            dev = DeviceScene(fs)
+            full, st = dev.render(cam, p)
+            rect, _ = dev.render(cam, p, rect=(37, 21, 203, 150))
+            slot = dev.lib.rt_tiles_owned(W, H, 32, 32, 0, 3)
+            allt = torch.zeros((3, slot * 32 * 32 * 3), dtype=torch.uint8, device="cuda")
+            batch = torch.zeros((3, H, W, 3), dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            for part in range(3):
+                dev.render_tiles_device(cam, p, (32, 32), part, 3, allt[part].data_ptr())
+            dev.render_batch_device(cams, p, batch.data_ptr(), H * W * 3)
+            dev.status()
+            torch.cuda.synchronize()
+            got[mode] = (full, st.trace_calls, rect, allt.cpu().numpy(), batch.cpu().numpy())
+    finally:
+        if saved is None:
+            os.environ.pop("RT_NO_FAST32", None)
+        else:
+            os.environ["RT_NO_FAST32"] = saved
+    a, b = got["fast"], got["wide"]
+    assert a[1] == b[1]
+    for k in (0, 2, 3, 4):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(a[4][0], a[0]) and not np.array_equal(a[4][1], a[0])
+
+
 def test_boundary_errors():
     fs = wl.scene_analytic()
     dev = DeviceScene(fs)
