@@ -302,8 +302,9 @@ __device__ __forceinline__ void quad_run(const DScene& S, QTrav& t, const Ray& r
             const uint32_t ref = __float_as_uint(a.w);
             bool h;
             float tn = slab(a.x, a.y, a.z, b.x, b.y, b.z, inv, ood, tcull, h);
+            // (the ballots of the two comparisons ANDed as scalars: the ballot of `h && ref != ...` goes through a VGPR)
+            const uint32_t bits = (uint32_t)((__builtin_amdgcn_ballot_w64(h) & __builtin_amdgcn_ballot_w64(ref != RT_NO_CHILD)) >> (lane & 60u)) & 15u;
             h = h && ref != RT_NO_CHILD;
-            const uint32_t bits = quad_bits(h, lane);
             const uint32_t n_hit = (uint32_t)__popc(bits);
             // rank of this lane's child among the hit ones, nearest first. tn >= 0, so its bit pattern orders like its
             // value; with the slot in the two lowest bits the four keys are distinct (the visiting order only affects
@@ -313,8 +314,18 @@ __device__ __forceinline__ void quad_run(const DScene& S, QTrav& t, const Ray& r
             // shadow rays do go in node order: their "nearest first" is the order of one ray of 64.)
             tn = h ? tn : FLT_MAX;
             const uint32_t key = (__float_as_uint(tn) & ~3u) | j;
-            const uint32_t rank = (uint32_t)(dpp_u<QP_ROT1>(key) < key) + (uint32_t)(dpp_u<QP_ROT2>(key) < key) +
-                                  (uint32_t)(dpp_u<QP_ROT3>(key) < key);
+            // (the borrow of `neighbour's key - key` IS the comparison: a subtract with the DPP move folded in and an
+            // add-with-carry per neighbour, six instructions where move + compare + select + add are nine; s_nop: a DPP
+            // operand written by the instruction before needs two wait states, and the compiler does not see in here)
+            uint32_t rank = 0, scratch_;
+            asm("s_nop 1\n\t"
+                "v_sub_co_u32_dpp %1, vcc, %2, %2 quad_perm:[1,2,3,0] row_mask:0xf bank_mask:0xf\n\t"
+                "v_addc_co_u32_e32 %0, vcc, 0, %0, vcc\n\t"
+                "v_sub_co_u32_dpp %1, vcc, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                "v_addc_co_u32_e32 %0, vcc, 0, %0, vcc\n\t"
+                "v_sub_co_u32_dpp %1, vcc, %2, %2 quad_perm:[3,0,1,2] row_mask:0xf bank_mask:0xf\n\t"
+                "v_addc_co_u32_e32 %0, vcc, 0, %0, vcc"
+                : "+v"(rank), "=&v"(scratch_) : "v"(key) : "vcc");
             // the nearest is visited next, the others are pushed so that the second nearest is on top
             if (h && rank > 0) qs[(sp + (int)n_hit - 1 - (int)rank) * 16] = ref;
             cur = quad_max_u((h && rank == 0) ? ref : 0u);     // a child reference is never 0 (node 0 is a root)
