@@ -237,7 +237,7 @@ extern "C" int rt_scene_create_ex(const rt_flat_scene* sc, int device, uint32_t 
     for (hipEvent_t& e : s->ev_sync)
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { rt_set_error("hipEventCreate failed"); return fail(RT_ERR_DEVICE); }
 
-    std::vector<uint4> objs(size_t(sc->n_objects) * 2);
+    std::vector<uint4> objs(size_t(sc->n_objects) * 2 + 2, make_uint4(0, 0, 0, 0));      // + one entry of zeros: the object loops fetch entry k + 1 while they work on k
     for (uint32_t i = 0; i < sc->n_objects; ++i) {
         const rt_object& o = sc->objects[i];
         float prm[4] = {0, 0, 0, 0}, inv_r = 0;

@@ -647,10 +647,13 @@ __device__ __forceinline__ int closest_loop(const DScene& S, const Ray& ray, boo
     V3 tmpnormal = mk(0, 0, 0);
     if (S.n_objects == 0) return susp;
     const bool counter = !QUAD || (lane_id() & 3u) == 0;
-    u32x4 ob = ldc4(S.objects, 0), pb = ldc4(S.objects, 1);
+    // (the table ends with an entry of zeros, so entry k + 1 always exists; a walking pointer: two scalar instructions
+    // per object where index, clamp, shift and add were seven)
+    const RT_CONSTANT u32x4* op = (const RT_CONSTANT u32x4*)(const void*)S.objects;
+    u32x4 ob = op[0], pb = op[1];
     for (uint32_t k = 0; k < S.n_objects; ++k) {
-        const uint32_t kn = k + 1 < S.n_objects ? k + 1 : k;
-        const u32x4 ob_n = ldc4(S.objects, 2 * kn), pb_n = ldc4(S.objects, 2 * kn + 1);
+        op += 2;
+        const u32x4 ob_n = op[0], pb_n = op[1];
         const float4 prm = as_f4(pb);
         const bool go = alive && k >= k0 && susp < 0;
         bool hit = false;
@@ -717,10 +720,13 @@ __device__ __forceinline__ bool occluded_loop(const DScene& S, const Ray& ray, b
     susp = -1;
     if (S.n_objects == 0) return in;
     const bool counter = !QUAD || (lane_id() & 3u) == 0;
-    u32x4 ob = ldc4(S.objects, 0), pb = ldc4(S.objects, 1);
+    // (the table ends with an entry of zeros, so entry k + 1 always exists; a walking pointer: two scalar instructions
+    // per object where index, clamp, shift and add were seven)
+    const RT_CONSTANT u32x4* op = (const RT_CONSTANT u32x4*)(const void*)S.objects;
+    u32x4 ob = op[0], pb = op[1];
     for (uint32_t k = 0; k < S.n_objects; ++k) {
-        const uint32_t kn = k + 1 < S.n_objects ? k + 1 : k;
-        const u32x4 ob_n = ldc4(S.objects, 2 * kn), pb_n = ldc4(S.objects, 2 * kn + 1);
+        op += 2;
+        const u32x4 ob_n = op[0], pb_n = op[1];
         const float4 prm = as_f4(pb);
         const bool go = alive && k >= k0 && !in && susp < 0;
         // (three separate tests of the wave-uniform type, not if / else if / else: the structurised chain carries flag
