@@ -636,6 +636,10 @@ __device__ __forceinline__ void serve_traverse(const DScene& S, uint32_t root, b
 // before the current one is worked on.
 // ---------------------------------------------------------------------------------------------------------
 struct HitState { float dist; V3 n; int cur; uint32_t mat; float tmpdist; };
+// First statement of a block guarded by a wave-uniform test: keeps that test a scalar branch of its own (s_cmp +
+// s_cbranch). Without it the compiler folds it into the per-lane condition inside the block - compare, select, and
+// with the lane mask, save exec, branch: five scalar instructions, paid by every object type for every object.
+#define RT_UNIFORM_BRANCH asm volatile("")
 
 // Closest-hit loop (reference src/raytracer.cpp:292-300): objects in scene order, strict <. Returns -1 when the loop
 // ran to its end, else (QUAD = false only) the index of the mesh object the ray suspended at, with `h` as it was
@@ -658,14 +662,17 @@ __device__ __forceinline__ int closest_loop(const DScene& S, const Ray& ray, boo
         const bool go = alive && k >= k0 && susp < 0;
         bool hit = false;
         if (ob.x == RT_OBJ_SPHERE) {
+            RT_UNIFORM_BRANCH;
             if (COUNT) wk.spheres += go && counter;
             if (go && !(S.debug & 16u)) hit = sphere_isect(prm, __uint_as_float(ob.w), ray, h.tmpdist, tmpnormal, coherent);
         }
         if (ob.x == RT_OBJ_PLANE) {
+            RT_UNIFORM_BRANCH;
             if (COUNT) wk.planes += go && counter;
             if (go && !(S.debug & 16u)) hit = plane_isect(prm, ray, h.tmpdist, tmpnormal);
         }
         if (ob.x != RT_OBJ_SPHERE && ob.x != RT_OBJ_PLANE) {      // (separate tests: see occluded_loop)
+            RT_UNIFORM_BRANCH;
             // Model::intersect (reference src/primitives.cpp:364-384): dist = FLT_MAX, bounding-sphere gate, closest
             // face, normal = (1-u-v)*n0 + u*n1 + v*n2 (primitives.cpp:80, not normalised)
             const ModelRef m = load_model(S.models, ob.y);
@@ -732,6 +739,7 @@ __device__ __forceinline__ bool occluded_loop(const DScene& S, const Ray& ray, b
         // (three separate tests of the wave-uniform type, not if / else if / else: the structurised chain carries flag
         // registers and undefined values from one branch to the next)
         if (ob.x == RT_OBJ_SPHERE) {
+            RT_UNIFORM_BRANCH;
             if (COUNT) wk.spheres += go && counter;
             if (go) {
                 const bool hit = sphere_isect(prm, __uint_as_float(ob.w), ray, tmpdist, tmpnormal, coherent);
@@ -739,6 +747,7 @@ __device__ __forceinline__ bool occluded_loop(const DScene& S, const Ray& ray, b
             }
         }
         if (ob.x == RT_OBJ_PLANE) {
+            RT_UNIFORM_BRANCH;
             if (COUNT) wk.planes += go && counter;
             if (go) {
                 const bool hit = plane_isect(prm, ray, tmpdist, tmpnormal);
@@ -746,6 +755,7 @@ __device__ __forceinline__ bool occluded_loop(const DScene& S, const Ray& ray, b
             }
         }
         if (ob.x != RT_OBJ_SPHERE && ob.x != RT_OBJ_PLANE) {
+            RT_UNIFORM_BRANCH;
             const ModelRef m = load_model(S.models, ob.y);
             bool need = go;
             if (m.bb.w >= 0) {
