@@ -63,6 +63,10 @@ struct Ray { V3 o, d; };
 // memory; through a plain pointer it falls back to per-lane vector loads whose latency sits in every object test.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define RT_CONSTANT __attribute__((address_space(4)))
+// First statement of a block guarded by a wave-uniform test: keeps that test a scalar branch of its own (s_cmp +
+// s_cbranch). Without it the compiler folds it into the per-lane condition inside the block - compare, select, and
+// with the lane mask, save exec, branch: five scalar instructions, paid by every object type for every object.
+#define RT_UNIFORM_BRANCH asm volatile("")
 __device__ __forceinline__ u32x4 ldc4(const void* base, uint32_t i16) {
     return *((const RT_CONSTANT u32x4*)(base) + i16);
 }
@@ -527,6 +531,7 @@ __device__ __forceinline__ void packet_traverse(const DScene& S, uint32_t root, 
 #pragma unroll
                     for (uint32_t dt = 0; dt < 2; ++dt) {
                         if (t0 + dt < cnt) {                                                     // wave-uniform
+                            RT_UNIFORM_BRANCH;
                             const float4 q0 = as_f4(lf[dt]), q1 = as_f4(lf[2 + dt]), q2 = as_f4(lf[4 + dt]);
                             float tt, u, v;
                             if (live && tri_isect(f4xyz(q0), f4xyz(q1), f4xyz(q2), ray, tt, u, v)) {
@@ -636,10 +641,6 @@ __device__ __forceinline__ void serve_traverse(const DScene& S, uint32_t root, b
 // before the current one is worked on.
 // ---------------------------------------------------------------------------------------------------------
 struct HitState { float dist; V3 n; int cur; uint32_t mat; float tmpdist; };
-// First statement of a block guarded by a wave-uniform test: keeps that test a scalar branch of its own (s_cmp +
-// s_cbranch). Without it the compiler folds it into the per-lane condition inside the block - compare, select, and
-// with the lane mask, save exec, branch: five scalar instructions, paid by every object type for every object.
-#define RT_UNIFORM_BRANCH asm volatile("")
 
 // Closest-hit loop (reference src/raytracer.cpp:292-300): objects in scene order, strict <. Returns -1 when the loop
 // ran to its end, else (QUAD = false only) the index of the mesh object the ray suspended at, with `h` as it was
