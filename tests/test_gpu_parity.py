@@ -269,6 +269,36 @@ def test_frame_parity(oracle_mod, case):
         assert not got[mask].any()
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_random_spheres_frames(oracle_mod, seed):
+    """Spheres of very different sizes and distances (radius 0.01 .. 30, up to 200 away, some behind the camera, some
+    around it), shadows and reflections on: pins the wave-uniform exit of the sphere test (rt_kernels.hip: sphere_isect,
+    `coherent`: a conservative bound on val3 decides that every ray of a wave misses before the exact test runs) - a hit
+    it dropped would change a pixel from sphere to background and the ray counts with it. Frames and ray counts against
+    the oracle; every silhouette in a 640 x 480 frame is a few thousand grazing rays."""
+    O = oracle_mod
+    rng = np.random.default_rng(seed)
+    fs = wl.FlatScene()
+    mats = wl.yaml_materials()
+    names = ["mirror", "m1", "glass", "red", "green", "blue"]
+    for k in range(10):
+        r = float(10.0 ** rng.uniform(-2.0, 1.5))
+        d = float(10.0 ** rng.uniform(0.0, 2.3))
+        ang = rng.uniform(-0.6, 0.6, 2)
+        c = (d * np.sin(ang[0]), d * np.sin(ang[1]), -d * np.cos(ang[0]) * np.cos(ang[1]) * (1.0 if k else -1.0))
+        fs.add_sphere(tuple(float(x) for x in c), r, mats[names[k % len(names)]])
+    fs.add_sphere((0.0, 0.0, 0.0), 250.0, mats["green"])      # the camera sits inside this one
+    wl.add_yaml_lights(fs)
+    cam, p = reference_camera(640, 480), Params(max_depth=3)
+    got, st1 = DeviceScene(fs).render(cam, p)
+    want, st2 = O.Oracle(fs).render(cam, p)
+    within1, equal, worst = frame_stats(got, want)
+    print(f"seed {seed}: within 1 LSB {within1:.6f}, equal {equal:.6f}, worst {worst}, rays {st1.trace_calls}+{st1.shadow_rays}")
+    assert st1.trace_calls == st2.trace_calls and st1.shadow_rays == st2.shadow_rays
+    assert list(st1.level_rays) == list(st2.level_rays)
+    assert within1 >= 0.9999
+
+
 def test_schedule_forms_agree(oracle_mod):
     """The same frame through the different launch schedules: first call of a scene (level sizes unknown: per-lane
     kernels + resumed queues at every level), second call (small levels run as one quad kernel), the asynchronous
