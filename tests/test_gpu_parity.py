@@ -100,6 +100,32 @@ def edge_rays(fs, n_faces, seed):
     return np.concatenate(rays).astype(np.float32)
 
 
+def far_rays(fs, n, seed):
+    """Rays at the centroids of faces of the first mesh from origins 10 .. 10,000 away, a third of them along one axis
+    exactly (two direction components 0) and a third in an axis plane (one component 0): the box tests run on a 1-ulp
+    reciprocal, +-1e-30 in place of a zero component and an 8-ulp far bound (rt_kernels.hip: slab, safe_rcp), and must
+    never cull a box whose triangle the exact test accepts."""
+    rng = np.random.default_rng(seed)
+    m = fs.meshes[0]
+    f = rng.integers(0, m.num_faces, n)
+    c = ((m.v[0][f] + m.v[1][f] + m.v[2][f]) * np.float32(1.0 / 3.0)).astype(np.float32)
+    dirs = rng.normal(size=(n, 3))
+    kind = np.arange(n) % 3
+    axis = rng.integers(0, 3, n)
+    for k in range(n):
+        if kind[k] == 1:
+            keep = dirs[k, axis[k]]; dirs[k] = 0.0; dirs[k, axis[k]] = keep if keep != 0 else 1.0
+        elif kind[k] == 2:
+            dirs[k, axis[k]] = 0.0
+    dirs /= np.sqrt((dirs * dirs).sum(axis=1, keepdims=True))
+    dist = 10.0 ** rng.uniform(1.0, 4.0, (n, 1))
+    o = (c.astype(np.float64) - dirs * dist).astype(np.float32)
+    d = c - o                                    # non-unit, exactly 0 where the origin was not moved
+    d[dirs == 0.0] = 0.0
+    dn = (d * (np.float32(1.0) / np.sqrt((d * d).sum(axis=1, keepdims=True)))).astype(np.float32)
+    return np.concatenate([np.concatenate([o, d], axis=1), np.concatenate([o, dn], axis=1)]).astype(np.float32)
+
+
 def doubled_faces_scene():
     """A mesh in which every face exists TWICE (and a third time displaced by a few ulps), the copies carrying
     different vertex normals: the normal that comes back says which face index won the tie."""
@@ -132,7 +158,7 @@ def test_intersect_forms_bit_exact(oracle_mod, scene_name, form):
     dev = DeviceScene(fs)
     orc = O.Oracle(fs)
     cam = reference_camera(256, 192)
-    rays = np.concatenate([camera_rays(O, cam, Params(), 1), random_rays(20000, 7), edge_rays(fs, 400, 3)])
+    rays = np.concatenate([camera_rays(O, cam, Params(), 1), random_rays(20000, 7), edge_rays(fs, 400, 3), far_rays(fs, 3000, 11)])
     mesh_obj = [k for k, o in enumerate(fs.objects) if o[0] == 2][0]
     for obj in (-1, mesh_obj):
         h2, d2, n2 = orc.intersect(rays, obj)
