@@ -163,8 +163,8 @@ int rt_render(rt_scene* scene, const rt_camera* cam, const rt_params* params,
 
 /* rt_render with a progress report. Replaces: the per-pixel `++finPix` of render() (reference src/raytracer.cpp:450)
  * that the reference's main thread turns into its pix/s line (src/raytracer.cpp:217-225). `progress(user, done, total)`
- * is called on the calling thread after every pass of the frame (a frame of up to 2^23 samples is one pass; an 8K frame
- * at 64 samples per pixel is 254) with the pixels of the rectangle finished so far, and once more with done == total
+ * is called on the calling thread after every pass of the frame (a frame of up to rt_scene_pass_samples() samples is one
+ * pass: 2^26 on an MI355X, where an 8K frame at 64 samples per pixel is 32 passes) with the pixels of the rectangle finished so far, and once more with done == total
  * when the bytes are in bgr_out. progress == NULL: rt_render. */
 typedef void (*rt_progress_fn)(void* user, uint64_t pixels_done, uint64_t pixels_total);
 int rt_render_progress(rt_scene* scene, const rt_camera* cam, const rt_params* params,
@@ -178,8 +178,10 @@ int rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_params* par
                      uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
                      uint8_t* d_bgr_out, void* stream, rt_stats* stats);
 
-/* rt_render_device for callers that CANNOT ALLOCATE (code under HIP graph capture, tight serving loops, harnesses that
- * forbid hipMalloc). No counterpart in the reference. Same kernels and schedule, asynchronous on `stream` (NULL: the
+/* rt_render_device for callers that CANNOT ALLOCATE (tight serving loops, harnesses that forbid hipMalloc, code that
+ * must not disturb an allocator's state). No counterpart in the reference. (Not meant to be CAPTURED into a hipGraph:
+ * the call orders its launches over the scene's own streams and copies the level sizes back as a scheduling hint for
+ * the next frame, which a replayed graph would freeze.) Same kernels and schedule, asynchronous on `stream` (NULL: the
  * scene's own), same bytes as rt_render_device; but the frame's node pool is not the scene's grow-only hipMalloc'ed
  * workspace, it is a fixed 20.5 MiB array that is part of the library's device image (one copy per GPU the library runs
  * on, held until the process ends), used in passes of 2^14 samples (12 pool entries per sample). The call performs no hipMalloc, hipFree or other
@@ -187,9 +189,11 @@ int rt_render_device(rt_scene* scene, const rt_camera* cam, const rt_params* par
  * must not exceed RT_NOALLOC_MAX_SAMPLES (2^21: a 1920x1080 frame at 1 sample per pixel fits), else RT_ERR_LIMIT.
  * Every call on one GPU - whatever the rt_scene - shares that GPU's array: calls that overlap on one GPU race; order
  * them on one stream or wait for the previous one. A frame whose ray trees outgrow the pool is reported by
- * rt_scene_status (RT_ERR_OVERFLOW) as for every asynchronous call: render it again, the scene has switched to passes
- * a quarter the size (4x the room per sample, down to 64-pixel passes; a scene that still overflows there needs
- * rt_render_device, whose pool can grow). */
+ * rt_scene_status (RT_ERR_OVERFLOW) as for every asynchronous call: render it again, this entry point has switched to
+ * passes a quarter the size for this scene (4x the room per sample, down to 64-pixel passes - the scene's ordinary
+ * calls are not affected; a frame of many small passes reuses the scene's 1024 pass-counter slots in turn). A frame
+ * that overflows even with 64-pixel passes is reported with a message that says so: it needs rt_render_device, whose
+ * pool can grow. */
 #define RT_NOALLOC_MAX_SAMPLES (1u << 21)
 int rt_render_device_noalloc(rt_scene* scene, const rt_camera* cam, const rt_params* params,
                              uint32_t x0, uint32_t y0, uint32_t w, uint32_t h,
@@ -335,6 +339,24 @@ int rt_trace_form(rt_scene* scene, int form, const rt_params* params, const floa
  * the scene's frames in flight. Results never depend on it. No counterpart in the reference (its recursion needs no
  * workspace); for callers that bound the scene's HBM use and for the multi-pass parity tests. */
 int rt_scene_set_pass_samples(rt_scene* scene, uint32_t samples);
+/* Fixes one choice of the launch schedule that the library otherwise makes from the scene, the samples per pixel and
+ * the level sizes of the previous frame. Results never depend on any of them (tests/test_gpu_parity.py renders one scene
+ * through the combinations and compares the bytes); they exist for those tests and for timing experiments. Waits for the
+ * scene's frames in flight. No counterpart in the reference. Names and values:
+ *   "packet"           -1 automatic | 0 level 0 by marks + quads | 1 level 0 as 64-ray packets | 2 packets at every large level
+ *   "large_threshold"  rays from which a bounce level runs as per-lane kernel + queue (-1: the built-in table)
+ *   "large_max_level"  deepest level that may do so (-1: built-in)
+ *   "serve"            bounce levels as per-lane kernels with quad service: 0 never | 1 always | -1 by pass size
+ *   "split_small"      runs of small levels shaded per lane + resuming quads (1, default) | one quad launch (0)
+ *   "tiny_run"         a run of at most this many hits is shaded by one quad launch (default 1024)
+ *   "tail_rays"        levels of at most this many rays go to the one-launch tail k_tail (0 = never, default)
+ *   "tail_workgroups"  workgroups of that launch
+ *   "index64"          1: sample-index arithmetic by 64-bit division even where 32 bits would do
+ *   "chunk_log2"       level-0 blocks per shard chunk
+ *   "graph"            1: asynchronous frames are captured into a hipGraph and replayed (measured slower)
+ * The environment variables of the same meaning (RT_PACKET, RT_LARGE_THR, ... tools/exp_*.sh) are read once, by
+ * rt_scene_create; no rendering call reads the environment. Unknown name or value out of range: RT_ERR_INVALID. */
+int rt_scene_set_option(rt_scene* scene, const char* name, int64_t value);
 uint32_t rt_scene_pass_samples(const rt_scene* scene);      /* the current value */
 
 /* BVH introspection for tests and the roofline's algorithmic bytes/flops. */

@@ -114,7 +114,7 @@ EXPORTS = [
     "rt_intersect_form", "rt_occluded_form", "rt_trace_form", "rt_scene_set_pass_samples",
     "rt_scene_bvh_info", "rt_bvh_check", "rt_scene_bvh_check", "rt_scene_status", "rt_scene_stream", "rt_set_count_work", "rt_get_work", "rt_last_error", "rt_version",
     "rt_render_progress", "rt_multi_create", "rt_multi_destroy", "rt_multi_parts", "rt_multi_scene", "rt_multi_render", "rt_multi_render_device",
-    "rt_multi_status", "rt_scene_pass_samples",
+    "rt_multi_status", "rt_scene_pass_samples", "rt_scene_set_option",
 ]
 
 PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint64, C.c_uint64)
@@ -176,6 +176,8 @@ def load(path=None):
     lib.rt_scene_set_pass_samples.argtypes = [vp, u32]
     lib.rt_scene_pass_samples.argtypes = [vp]
     lib.rt_scene_pass_samples.restype = u32
+    if hasattr(lib, "rt_scene_set_option"):      # (absent from round-2 builds of the library: tools/exp_ab_builds.sh A/B runs)
+        lib.rt_scene_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
     lib.rt_scene_bvh_info.argtypes = [vp, C.POINTER(rt_bvh_info)]
     lib.rt_bvh_check.argtypes = [C.POINTER(rt_flat_scene), C.POINTER(rt_bvh_check_result)]
     lib.rt_scene_bvh_check.argtypes = [vp, C.POINTER(rt_flat_scene), C.POINTER(rt_bvh_check_result)]

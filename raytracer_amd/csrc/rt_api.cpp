@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "raytracer_amd.h"
@@ -62,16 +63,72 @@ struct PassCounters {                 // one per pass, zeroed by one memset per 
 // Larger passes are faster - the bounce levels of a pass are a chain of dependent launches whose sizes grow with it:
 // 4K 16 spp glass scene 38.2 ms per frame at 2^23, 36.6 at 2^24, 34.1 at 2^25, 32.0 at 2^26; 10 M-triangle field at 8K 64 spp
 // 634 / 614 / 609 ms - and cost 672 B of workspace per sample (5.4 GB at 2^23, 45 GB at 2^26). So: the largest power of
-// two up to 2^26 whose workspace stays below a fifth of the device's memory (2^26 on the 288 GB of an MI355X), at least
-// 2^23. A frame with fewer samples is one pass and allocates for what it has.
-static uint32_t default_pass_samples() {
-    if (const char* e = std::getenv("RT_PASS_LOG2")) return 1u << std::max(RT_PASS_LOG2_MIN, std::min(RT_PASS_LOG2_MAX, std::atoi(e)));
+// two up to 2^26 whose workspace stays below a quarter of what is FREE on the device when the scene is created (2^26 on
+// an MI355X with 180 GB or more to spare; a process that keeps several scenes in flight on a device others use too gets
+// smaller passes instead of taking memory it was never given), at least 2^23. A frame with fewer samples is one pass
+// and allocates for what it has; the workspace itself is allocated by the first frame that needs it.
+static uint32_t default_pass_samples(int env_log2) {
+    if (env_log2 >= 0) return 1u << std::max(RT_PASS_LOG2_MIN, std::min(RT_PASS_LOG2_MAX, env_log2));
     size_t free_b = 0, total_b = 0;
     int k = 23;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-        while (k < RT_PASS_LOG2_MAX && (uint64_t(672) << (k + 1)) <= total_b / 5u) ++k;
+        while (k < RT_PASS_LOG2_MAX && (uint64_t(672) << (k + 1)) <= std::min(free_b, total_b) / 4u) ++k;
     else (void)hipGetLastError();
     return 1u << k;
+}
+
+// What a caller (a test, an experiment) may fix about the schedule instead of leaving it to the scene and the level
+// sizes: rt_scene_set_option. The same names in upper case with an RT_ prefix in the environment are read ONCE, when a
+// scene is created (tools/exp_*.sh); no call that renders reads the environment.
+struct Knobs {
+    int packet = -1;              // RT_PACKET: -1 by samples per pixel; 0 marks + quads at level 0; 1 packets at level 0; 2 at every large level
+    long long large_thr = -1;     // RT_LARGE_THR: rays from which a bounce level runs as per-lane kernel (+ queue); -1: expect_large's table
+    int large_maxlv = -1;         // RT_LARGE_MAXLV: deepest level that may be "large"; -1 default
+    int serve = -1;               // RT_SERVE: bounce levels by quad service: 0 never, 1 always, -1 by pass size
+    int split_small = 1;          // RT_SPLIT_SMALL: runs of small levels shaded per lane + resuming quads (1) / one quad launch (0)
+    int tiny_run = 1024;          // RT_TINY_RUN: a run of at most this many hits is one quad launch
+    long long tail = 0;           // RT_TAIL: levels of at most this many rays go to k_tail (0: never)
+    int tail_wg = RT_TAIL_MAX_WG; // RT_TAIL_WG
+    int index64 = 0;              // RT_NO_FAST32: sample index arithmetic by 64-bit division even where 32 bits would do
+    int chunk_log2 = RT_SHARD_CHUNK_LOG2;   // RT_CHUNK_LOG2
+    int use_graph = 0;            // RT_USE_GRAPH: replay asynchronous frames as a hipGraph (measured slower)
+    int grid0 = 0;                // RT_GRID0: cap of the level-0 per-lane grids (0: none)
+    int pass_log2 = -1;           // RT_PASS_LOG2
+    int shade_streams = 3;        // RT_SHADE_STREAMS
+#ifdef RT_EXPERIMENTS
+    uint32_t debug = 0;           // RT_DEBUG_SKIP: parts of the kernels switched off (timing experiments; WRONG frames)
+    int wave_log_level = -1;      // RT_WAVE_LOG=<level>:<file>
+    bool wave_log_shade = false;  // RT_WAVE_LOG_SHADE
+    std::string wave_log_path, tail_log_path;   // RT_TAIL_LOG=<file>
+#endif
+};
+static long long env_ll(const char* name, long long dflt) { const char* e = std::getenv(name); return e ? std::atoll(e) : dflt; }
+static Knobs knobs_from_env() {
+    Knobs k;
+    k.packet = int(env_ll("RT_PACKET", k.packet));
+    k.large_thr = env_ll("RT_LARGE_THR", k.large_thr);
+    k.large_maxlv = int(env_ll("RT_LARGE_MAXLV", k.large_maxlv));
+    k.serve = int(env_ll("RT_SERVE", k.serve));
+    k.split_small = int(env_ll("RT_SPLIT_SMALL", k.split_small));
+    k.tiny_run = int(std::max(0ll, env_ll("RT_TINY_RUN", k.tiny_run)));
+    k.tail = std::max(0ll, env_ll("RT_TAIL", k.tail));
+    k.tail_wg = int(std::min<long long>(RT_TAIL_MAX_WG, std::max(2ll, env_ll("RT_TAIL_WG", k.tail_wg)))) & ~1;
+    k.index64 = std::getenv("RT_NO_FAST32") ? 1 : 0;
+    k.chunk_log2 = int(std::min<long long>(RT_SHARD_CHUNK_LOG2_MAX, std::max(0ll, env_ll("RT_CHUNK_LOG2", k.chunk_log2))));
+    k.use_graph = std::getenv("RT_USE_GRAPH") ? 1 : 0;
+    k.grid0 = int(std::max(0ll, env_ll("RT_GRID0", 0)));
+    k.pass_log2 = int(env_ll("RT_PASS_LOG2", -1));
+    k.shade_streams = int(std::max(1ll, std::min(3ll, env_ll("RT_SHADE_STREAMS", 3))));
+#ifdef RT_EXPERIMENTS
+    k.debug = uint32_t(env_ll("RT_DEBUG_SKIP", 0));
+    if (const char* e = std::getenv("RT_WAVE_LOG")) {
+        k.wave_log_level = std::atoi(e);
+        if (const char* c = std::strchr(e, ':')) k.wave_log_path = c + 1; else k.wave_log_level = -1;
+    }
+    k.wave_log_shade = std::getenv("RT_WAVE_LOG_SHADE") != nullptr;
+    if (const char* e = std::getenv("RT_TAIL_LOG")) k.tail_log_path = e;
+#endif
+    return k;
 }
 #define RT_POOL_FACTOR 6u             // node pool = 6x the pass size when materials bounce (level 0 + 5x for deeper levels)
 #define RT_MAX_TIMED 2048
@@ -82,7 +139,8 @@ enum { RT_K_EXTEND_WIDE = 0, RT_K_SHADE_WIDE = 1, RT_K_EXTEND_QUAD = 2, RT_K_SHA
 struct rt_scene {
     int device = 0;
     hipStream_t stream = nullptr;
-    int n_shade_streams = 3;             // RT_SHADE_STREAMS in the environment (experiments): 1..3
+    Knobs knobs;                         // rt_scene_set_option / the environment when the scene was created
+    int n_shade_streams = 3;             // Knobs::shade_streams (the streams exist from the start): 1..3
     hipStream_t shade_stream[3] = {nullptr, nullptr, nullptr};   // the shade kernels run here, next to the extend kernels:
                                                                  // large levels on [level & 1], runs of small levels on [2]
     hipEvent_t ev_sync[2 * RT_MAX_LEVELS + 5] = {};      // per level: per-lane extend done, quad extend done; joins
@@ -95,6 +153,7 @@ struct rt_scene {
     uint32_t pool_cap = 0, sub_cap = 0, ws_n0 = 0;
     uint32_t n_leaves = 0, bvh_stack = 0;
     bool packet_auto = true;             // DScene::packet chosen per frame (render_frame)
+    bool no_packets_flag = false;        // created with RT_SCENE_NO_PACKETS: option "packet" cannot bring them back
     bool built_on_device = false;
     double build_seconds = 0;
     std::vector<uint32_t> model_roots;
@@ -126,6 +185,8 @@ struct rt_scene {
     int last_overflow = 0;
     uint32_t* h_overflow = nullptr;      // pinned, written by k_resolve: an asynchronous frame ran out of pool
     uint32_t shrink_log2 = 0;            // passes are cut 2^k times smaller than RT_PASS_SAMPLES: learned from overflows, sticky
+    uint32_t noalloc_shrink_log2 = 0;    // the same for rt_render_device_noalloc's passes of the static pool (its overflows teach only it)
+    bool last_noalloc = false;           // the most recent asynchronous frame used the static pool
     hipStream_t last_stream = nullptr;   // stream of the most recent asynchronous frame
     uint32_t last_spp = 1;
     uint32_t ws_min_n0 = 0;              // the workspace is sized for at least this many samples per pass (grown after overflows)
@@ -222,6 +283,7 @@ extern "C" int rt_scene_create_ex(const rt_flat_scene* sc, int device, uint32_t 
 
     rt_scene* s = new rt_scene();
     s->device = device;
+    s->knobs = knobs_from_env();         // the only place the environment is read
     auto fail = [&](int code) { bvh_free(&bvh); hipFree(dbvh.nodes); hipFree(dbvh.leaves); free_scene(s); return code; };
     // (no stream priorities: low-priority shade streams gained ~1.5 % but hung hipDeviceSynchronize when two processes
     // shared one GPU)
@@ -233,7 +295,7 @@ extern "C" int rt_scene_create_ex(const rt_flat_scene* sc, int device, uint32_t 
         hipStreamCreateWithFlags(&s->shade_stream[0], hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&s->shade_stream[1], hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&s->shade_stream[2], hipStreamNonBlocking) != hipSuccess) { rt_set_error("hipStreamCreate failed"); return fail(RT_ERR_DEVICE); }
-    if (const char* e = std::getenv("RT_SHADE_STREAMS")) s->n_shade_streams = std::max(1, std::min(3, std::atoi(e)));
+    s->n_shade_streams = s->knobs.shade_streams;
     for (hipEvent_t& e : s->ev_sync)
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { rt_set_error("hipEventCreate failed"); return fail(RT_ERR_DEVICE); }
 
@@ -286,19 +348,17 @@ extern "C" int rt_scene_create_ex(const rt_flat_scene* sc, int device, uint32_t 
     }
     s->d.n_lights = sc->n_lights;
     // Level 0 as packets (packet_traverse). Measured faster even where triangles are much smaller than pixels (10 M
-    // faces at 1080p 4 spp: 7.4 -> 6.4 ms/frame). RT_PACKET=0 in the environment turns it off (experiments).
+    // faces at 1080p 4 spp: 7.4 -> 6.4 ms/frame). Option "packet" (rt_scene_set_option) fixes the choice.
     s->packet_auto = true;
     s->d.packet = sc->n_models > 0 ? 1u : 0u;
-    if (const char* e = std::getenv("RT_PACKET")) { s->d.packet = sc->n_models > 0 ? uint32_t(std::atoi(e)) : 0u; s->packet_auto = false; }
-    if (flags & RT_SCENE_NO_PACKETS) { s->d.packet = 0; s->packet_auto = false; }
+    if (s->knobs.packet >= 0) { s->d.packet = sc->n_models > 0 ? uint32_t(s->knobs.packet) : 0u; s->packet_auto = false; }
+    if (flags & RT_SCENE_NO_PACKETS) { s->d.packet = 0; s->packet_auto = false; s->no_packets_flag = true; }
     s->d.user_packet = 0;
-    s->pass_samples = default_pass_samples();
+    s->pass_samples = default_pass_samples(s->knobs.pass_log2);
     // set-up for rt_render_device_noalloc: the address of the static workspace ON THIS DEVICE (current since hipSetDevice
-    // above), asked once per device and kept; the entry point itself then allocates and looks up nothing
-    if (hipError_t e = noalloc_scratch(device, &s->noalloc_ws); e != hipSuccess) {
-        rt_set_error("hipGetSymbolAddress(scratch) failed on device %d: %s", device, hipGetErrorString(e));
-        return fail(RT_ERR_DEVICE);
-    }
+    // above), asked once per device and kept; the entry point itself then allocates and looks up nothing. A device on
+    // which this fails (index beyond the table, no symbol) still gets its scene: only that entry point then reports it.
+    if (hipError_t e = noalloc_scratch(device, &s->noalloc_ws); e != hipSuccess) { s->noalloc_ws = nullptr; (void)hipGetLastError(); }
     s->aa_cache.reserve(2 * RT_MAX_AA_POINTS);      // so that a new anti-aliasing pattern never allocates
     if ((rc = upload(s, objs.data(), objs.size(), &s->d.objects)) != RT_OK) return fail(rc);
     if ((rc = upload(s, models.data(), models.size(), &s->d.models)) != RT_OK) return fail(rc);
@@ -354,10 +414,17 @@ extern "C" int rt_scene_status(rt_scene* s) {
     HIP_TRY(hipStreamSynchronize(s->stream));
     if (s->copy_stream) HIP_TRY(hipStreamSynchronize(s->copy_stream));
     const bool over = *s->h_overflow != 0 || s->last_overflow == 1;
+    // a frame in the static pool that overflowed although its passes were already 64 pixels has nowhere to go
+    const bool at_floor = over && s->last_noalloc &&
+        (std::max<uint32_t>(64u, RT_NOALLOC_PASS_SAMPLES / std::max<uint32_t>(1u, s->last_spp)) >> s->noalloc_shrink_log2) <= 64u;
     if (*s->h_overflow && s->last_overflow != 1) learn_from_overflow(s, std::max<uint32_t>(64u, RT_PASS_SAMPLES / std::max<uint32_t>(1u, s->last_spp)));   // not yet accounted for
     *s->h_overflow = 0;
     s->last_overflow = 0;
-    if (over) { rt_set_error("an asynchronous frame ran out of ray pool; the scene now uses smaller passes: render it again"); return RT_ERR_OVERFLOW; }
+    if (over) {
+        if (at_floor) rt_set_error("an asynchronous frame ran out of ray pool in the static workspace even with 64-pixel passes: use rt_render_device, whose pool can grow");
+        else rt_set_error("an asynchronous frame ran out of ray pool; the scene now uses smaller passes: render it again");
+        return RT_ERR_OVERFLOW;
+    }
     return RT_OK;
 }
 
@@ -365,7 +432,7 @@ extern "C" void* rt_scene_stream(const rt_scene* s) { return s ? static_cast<voi
 
 extern "C" int rt_scene_set_pass_samples(rt_scene* s, uint32_t samples) {
     if (!s) { rt_set_error("null scene"); return RT_ERR_INVALID; }
-    if (samples == 0) { s->pass_samples = default_pass_samples(); return RT_OK; }
+    if (samples == 0) { HIP_TRY(hipSetDevice(s->device)); s->pass_samples = default_pass_samples(s->knobs.pass_log2); s->shrink_log2 = 0; return RT_OK; }
     if (samples < (1u << RT_PASS_LOG2_MIN) || samples > (1u << RT_PASS_LOG2_MAX) || (samples & (samples - 1u))) {
         rt_set_error("pass size %u is not a power of two in [2^%d, 2^%d]", samples, RT_PASS_LOG2_MIN, RT_PASS_LOG2_MAX);
         return RT_ERR_LIMIT;
@@ -379,6 +446,34 @@ extern "C" int rt_scene_set_pass_samples(rt_scene* s, uint32_t samples) {
 }
 
 extern "C" uint32_t rt_scene_pass_samples(const rt_scene* s) { return s ? s->pass_samples : 0u; }
+
+extern "C" int rt_scene_set_option(rt_scene* s, const char* name, int64_t value) {
+    if (!s || !name) { rt_set_error("null argument"); return RT_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(s->device));
+    if (s->last_stream) HIP_TRY(hipStreamSynchronize(s->last_stream));      // frames in flight keep their schedule
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    Knobs& k = s->knobs;
+    const std::string n(name);
+    if (n == "packet") {
+        if (value < -1 || value > 2) { rt_set_error("option packet: -1 (automatic), 0, 1 or 2"); return RT_ERR_INVALID; }
+        k.packet = int(value);
+        if (s->no_packets_flag) return RT_OK;      // RT_SCENE_NO_PACKETS stands
+        s->packet_auto = value < 0;
+        s->d.packet = s->n_models ? uint32_t(value < 0 ? 1 : value) : 0u;
+    }
+    else if (n == "large_threshold") k.large_thr = value < 0 ? -1 : value;
+    else if (n == "large_max_level") k.large_maxlv = value < 0 ? -1 : int(std::min<int64_t>(value, RT_MAX_LEVELS));
+    else if (n == "serve") k.serve = value < 0 ? -1 : (value ? 1 : 0);
+    else if (n == "split_small") k.split_small = value ? 1 : 0;
+    else if (n == "tiny_run") k.tiny_run = int(std::max<int64_t>(0, std::min<int64_t>(value, 1 << 30)));
+    else if (n == "tail_rays") k.tail = std::max<int64_t>(0, value);
+    else if (n == "tail_workgroups") k.tail_wg = int(std::min<int64_t>(RT_TAIL_MAX_WG, std::max<int64_t>(2, value))) & ~1;
+    else if (n == "index64") k.index64 = value ? 1 : 0;
+    else if (n == "chunk_log2") k.chunk_log2 = int(std::min<int64_t>(RT_SHARD_CHUNK_LOG2_MAX, std::max<int64_t>(0, value)));
+    else if (n == "graph") k.use_graph = value ? 1 : 0;
+    else { rt_set_error("unknown option '%s'", name); return RT_ERR_INVALID; }
+    return RT_OK;
+}
 
 extern "C" int rt_scene_bvh_info(const rt_scene* s, rt_bvh_info* out) {
     if (!s || !out) { rt_set_error("null argument"); return RT_ERR_INVALID; }
@@ -490,6 +585,8 @@ struct FrameJob {
     float ms_by[RT_N_KINDS];           // drained event pairs, summed per kind
     uint32_t launches_by[RT_N_KINDS];
     uint32_t n_pass_used;
+    bool noalloc;            // the pool is the static array
+    uint32_t slots_cleared;  // the first so many PassCounters slots were cleared at the start of the frame
     uint32_t large_mask;     // bit k: level k runs as per-lane kernel + queue (expect_large at the start of the frame)
     rt_progress_fn progress; // synchronous frames: called as the passes complete (rt_render_progress)
     void* progress_user;
@@ -553,11 +650,10 @@ static bool expect_large(const rt_scene* s, uint32_t pass, int lo, int hi) {
     // field at 8K 64 spp, every level from 1 M on: 520 ms; level 1 only: 468; levels 1 and 2 from 1 M: 525, level 2 from
     // 8 M: 470; no packets below level 0: 603. The 4K glass scene, whose level 2 holds 9 M rays per pass: every level
     // 29.7 ms, level 1 only 29.7, levels 1 and 2 28.9.)
-    const char* e = std::getenv("RT_LARGE_THR");      // experiments and tests: one threshold for the levels up to RT_LARGE_MAXLV
-    const char* em = std::getenv("RT_LARGE_MAXLV");
-    const int max_lv = em ? std::atoi(em) : (e || s->d.packet < 2) ? RT_MAX_LEVELS : 2;
+    const bool fixed = s->knobs.large_thr >= 0;       // option "large_threshold" (experiments and tests): one threshold for the levels up to "large_max_level"
+    const int max_lv = s->knobs.large_maxlv >= 0 ? s->knobs.large_maxlv : (fixed || s->d.packet < 2) ? RT_MAX_LEVELS : 2;
     for (int l = lo; l <= hi && l <= max_lv; ++l) {
-        const uint64_t thr = e ? uint64_t(std::atoll(e)) : s->d.packet >= 2 ? (l == 1 ? (1u << 20) : (8u << 20)) : s->d.packet == 1 ? ~0ull : 16u * RT_LEVEL_GRID;
+        const uint64_t thr = fixed ? uint64_t(s->knobs.large_thr) : s->d.packet >= 2 ? (l == 1 ? (1u << 20) : (8u << 20)) : s->d.packet == 1 ? ~0ull : 16u * RT_LEVEL_GRID;
         if (level_hint(s, pass, l) > thr) return true;
     }
     return false;
@@ -620,19 +716,30 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
     const uint32_t spp = J.base.spp;
     const bool meshes = s->n_models > 0;
     for (uint64_t done = 0; done < npx; done += pass_px) {
-        if (J.n_pass_used >= RT_MAX_PASSES) { rt_set_error("frame needs more than %d passes", RT_MAX_PASSES); return RT_ERR_LIMIT; }
+        // A synchronous frame reads every pass' counters back, so its passes need a slot each. An asynchronous frame reads
+        // none (k_resolve raises the host flag): its passes take the slots in turn, and a slot that comes round again is
+        // cleared on the frame's stream first - everything that used it is behind that point: a pass ends with its shade
+        // streams joined into this stream, its folds, its resolve and the copy of its hints.
+        if (J.n_pass_used >= RT_MAX_PASSES && recs) { rt_set_error("frame needs more than %d passes", RT_MAX_PASSES); return RT_ERR_LIMIT; }
         const uint32_t cnt = uint32_t(std::min<uint64_t>(pass_px, npx - done));
-        const uint32_t slot = J.n_pass_used++;
+        const uint32_t slot = J.n_pass_used % RT_MAX_PASSES;
         PassCounters* pc = s->d_counters + slot;
+        if (J.n_pass_used >= J.slots_cleared) HIP_TRY(hipMemsetAsync(pc, 0, sizeof(PassCounters), J.st));
+        ++J.n_pass_used;
         LevelArgs A = J.base;
         A.n0 = cnt * spp;
         A.sample0 = (px0 + done) * spp;
-        A.fast32 = (A.sample0 + A.n0 <= 0xFFFFFFFFull && !std::getenv("RT_NO_FAST32")) ? 1u : 0u;      // (the variable: tests of the 64-bit path)
+        A.fast32 = (A.sample0 + A.n0 <= 0xFFFFFFFFull && !s->knobs.index64) ? 1u : 0u;      // (option "index64": tests of the 64-bit path)
         A.sc = pc->sc;
         A.cancelled = pc->cancel;
         A.host_overflow = s->h_overflow;
         // small passes: smaller level-0 chunks, so that all shards (sub-pools) get their share of the entries
         while (A.chunk_log2 > 0 && (A.n0 >> (6u + A.chunk_log2)) < RT_SHARDS) --A.chunk_log2;
+        // The static pool cannot grow, so there a pass of fewer 64-sample blocks than shards, which uses only that many
+        // sub-pools, shares the whole pool among them: cutting a pass further (after an overflow) keeps giving more room per
+        // sample down to the 64-pixel pass. (The ordinary path grows its pool instead: render_frame's retry loop.)
+        if (const uint32_t n_blocks = (A.n0 + 63u) >> 6; J.noalloc && A.chunk_log2 == 0 && n_blocks < RT_SHARDS)
+            A.sub_cap = uint32_t(uint64_t(A.sub_cap) * RT_SHARDS / n_blocks);
         A.overflow = &pc->overflow;
         A.shadow_count = pc->shadow;
         A.work = &pc->work[0][0][0];
@@ -640,7 +747,7 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
         const bool overlap = !J.timed;
         hipStream_t sa = J.st;
         uint32_t grid0 = (A.n0 + RT_BLOCK - 1) / RT_BLOCK;
-        if (const char* e = std::getenv("RT_GRID0")) grid0 = std::min<uint32_t>(grid0, uint32_t(std::max(1, std::atoi(e))));      // experiments
+        if (s->knobs.grid0) grid0 = std::min<uint32_t>(grid0, uint32_t(s->knobs.grid0));      // experiments
         const uint32_t grid0q = std::min<uint32_t>((A.n0 + 15) / 16, 4u * RT_LEVEL_GRID);
         int rc;
         bool used_shade[3] = {false, false, false};
@@ -651,19 +758,18 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
         auto record = [&](int slot) -> hipError_t { ++ev_gen[slot]; return hipEventRecord(s->ev_sync[slot], sa); };
         // (a "lean" schedule for small passes - one shade stream, one shade launch for all small levels, deep levels folded
         // by one workgroup, 30 API calls instead of 50 - was measured SLOWER: 0.27 vs 0.24 ms for an eighth of the frame)
-        // diagnostics: RT_WAVE_LOG=<level>:<file> dumps per-workgroup timing of that level's quad extend kernel (COUNT builds)
         uint4* wave_log = nullptr;
         int log_level = -1;
-        const bool log_shade = std::getenv("RT_WAVE_LOG_SHADE") != nullptr;      // the level's per-lane shade kernel instead of its extend kernel
-        const char* log_path = nullptr;
-        {
-            if (const char* e = std::getenv("RT_WAVE_LOG")) {
-                log_level = std::atoi(e);
-                log_path = std::strchr(e, ':');
-                if (log_path) { ++log_path; hipMalloc(reinterpret_cast<void**>(&wave_log), sizeof(uint4) * 4u * RT_LEVEL_GRID); }
-                if (wave_log) hipMemsetAsync(wave_log, 0, sizeof(uint4) * 4u * RT_LEVEL_GRID, sa);
-            }
+        bool log_shade = false;
+#ifdef RT_EXPERIMENTS
+        // diagnostics: RT_WAVE_LOG=<level>:<file> dumps per-workgroup timing of that level's quad extend kernel (COUNT builds)
+        log_shade = s->knobs.wave_log_shade;      // the level's per-lane shade kernel instead of its extend kernel
+        if (s->knobs.wave_log_level >= 0) {
+            log_level = s->knobs.wave_log_level;
+            hipMalloc(reinterpret_cast<void**>(&wave_log), sizeof(uint4) * 4u * RT_LEVEL_GRID);
+            if (wave_log) hipMemsetAsync(wave_log, 0, sizeof(uint4) * 4u * RT_LEVEL_GRID, sa);
         }
+#endif
         // shade launch `form` over levels lo..hi on the level's shade stream, after event `after` of stream A
         auto shade = [&](int form, int lo, int hi, int after, bool small_run = false) -> int {
             const int which = ((form == RT_FORM_QUAD_FRESH || small_run) ? 2 : (lo & 1)) % s->n_shade_streams;
@@ -699,11 +805,11 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
         // extend and shade (fewest instructions: bunny_1080p in batches 0.326 -> 0.302 ms, c1 0.089 -> 0.080, 10 M-triangle
         // field 5.40 -> 5.22); a smaller pass keeps one ray per quad, whose waves are a quarter as long (one 1080p frame at
         // a time: 0.73 ms against 0.91 with quad service). RT_SERVE=0/1 overrides.
-        const int serve_env = std::getenv("RT_SERVE") ? std::atoi(std::getenv("RT_SERVE")) : -1;
+        const int serve_env = s->knobs.serve;
             // (Scenes with packets at every level, 16+ spp: their small bounce levels only from 32 M-sample passes on - 4K glass
         // scene at 2^26 32.0 -> 31.0 ms, at 2^25 34.1 -> 33.1; 10 M-triangle field at 8K: 2^23 632 -> 673 ms, 2^26 the same.)
         const bool serve = s->d.packet >= 1 && (serve_env >= 0 ? serve_env != 0 : (A.n0 >= (s->d.packet == 1 ? (4u << 20) : (32u << 20))));
-        const bool split_small = std::getenv("RT_SPLIT_SMALL") ? std::atoi(std::getenv("RT_SPLIT_SMALL")) != 0 : true;
+        const bool split_small = s->knobs.split_small != 0;
         auto shade_small = [&](int lo, int hi, int after) -> int {
             // (not where the per-lane kernels traverse meshes as packets at every level: the rays of a small bounce level
             // have nothing in common - 10 M-triangle field at 8K 64 spp 717 -> 970 ms)
@@ -711,30 +817,25 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
             if (!split_small || s->d.packet >= 2) return shade(RT_FORM_QUAD_FRESH, lo, hi, after);
             // a run of a few hundred hits: two launches would cost more than the instructions one quad launch repeats
             {
-                static const int tiny_default = 1024;
-                const char* e = std::getenv("RT_TINY_RUN");
                 uint64_t n = 0;
                 for (int l = lo; l <= hi; ++l) n += level_hint(s, slot, l);
-                if (n <= uint64_t(e ? std::max(0, std::atoi(e)) : tiny_default)) return shade(RT_FORM_QUAD_FRESH, lo, hi, after);
+                if (n <= uint64_t(s->knobs.tiny_run)) return shade(RT_FORM_QUAD_FRESH, lo, hi, after);
             }
             const int rc2 = shade(RT_FORM_WIDE, lo, hi, after, true);
             if (rc2 != RT_OK) return rc2;
             return shade(RT_FORM_QUAD_RESUME, lo, hi, after, true);
         };
         int small_lo = -1;      // first level of the run of small levels not shaded yet
-        // The tail (opt-in, RT_TAIL=<rays>): from the first level on behind which every level is expected to hold at most
+        // The tail (opt-in, option "tail_rays"): from the first level on behind which every level is expected to hold at most
         // that many rays, closest hits, light loops and folds of all those levels are ONE launch (k_tail) on the caller's
         // stream instead of two to three dependent launches per level. Same bytes; measured SLOWER on MI355X (bunny_1080p
         // one frame at a time 0.71 -> 0.75 ms with levels 3..10 in the tail, batched 0.296 -> 0.337): a level costs the
         // latency of its longest ray (12-35 us) either way, and a grid barrier across the 8 XCDs (L2 write-back, agent-
         // scope atomic and poll, invalidate: 6-9 us, then cold caches) is no cheaper than a launch boundary (~5 us).
         int lv_tail = levels + 1;
-        uint32_t tail_wg = RT_TAIL_MAX_WG;
+        const uint32_t tail_wg = uint32_t(s->knobs.tail_wg);
         {
-            static const int tail_default = 0;
-            const char* e = std::getenv("RT_TAIL");      // experiments and tests: rays per level, 0 = never
-            const uint64_t thr = uint64_t(e ? std::max(0, std::atoi(e)) : tail_default);
-            if (const char* w = std::getenv("RT_TAIL_WG")) tail_wg = std::min<uint32_t>(RT_TAIL_MAX_WG, std::max(2, std::atoi(w))) & ~1u;
+            const uint64_t thr = uint64_t(s->knobs.tail);      // experiments and tests: rays per level, 0 = never
             if (meshes && thr && !s->count_work && !wave_log)
                 while (lv_tail > 1 && level_hint(s, slot, lv_tail - 1) <= thr) --lv_tail;
         }
@@ -746,20 +847,23 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
                     small_lo = -1;
                 }
                 LevelArgs T = A;
-                uint4* tail_log = nullptr;
-                const char* tl = std::getenv("RT_TAIL_LOG");      // diagnostics: per-phase times of two E workgroups -> file
-                if (tl && hipMalloc(reinterpret_cast<void**>(&tail_log), sizeof(uint4) * 128) == hipSuccess) {
+#ifdef RT_EXPERIMENTS
+                uint4* tail_log = nullptr;      // diagnostics (RT_TAIL_LOG): per-phase times of two E workgroups -> file
+                if (!s->knobs.tail_log_path.empty() && hipMalloc(reinterpret_cast<void**>(&tail_log), sizeof(uint4) * 128) == hipSuccess) {
                     hipMemsetAsync(tail_log, 0, sizeof(uint4) * 128, sa);
                     T.wave_log = tail_log;
                 }
+#endif
                 if ((rc = timed_launch(J, sa, RT_K_EXTEND_QUAD, [&] { launch_tail(s->d, T, lv_tail, levels, pc->tail_bar, tail_wg, sa); })) != RT_OK) return rc;
+#ifdef RT_EXPERIMENTS
                 if (tail_log) {
                     uint4 h[128];
                     hipStreamSynchronize(sa);
                     hipMemcpy(h, tail_log, sizeof h, hipMemcpyDeviceToHost);
-                    if (FILE* f = std::fopen(tl, "wb")) { std::fwrite(h, sizeof(uint4), 128, f); std::fclose(f); }
+                    if (FILE* f = std::fopen(s->knobs.tail_log_path.c_str(), "wb")) { std::fwrite(h, sizeof(uint4), 128, f); std::fclose(f); }
                     hipFree(tail_log);
                 }
+#endif
                 break;
             }
             LevelArgs B = A;
@@ -807,13 +911,15 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
                 }
             }
         }
+#ifdef RT_EXPERIMENTS
         if (wave_log) {
             std::vector<uint4> h(4u * RT_LEVEL_GRID);
             hipStreamSynchronize(sa);
             hipMemcpy(h.data(), wave_log, sizeof(uint4) * h.size(), hipMemcpyDeviceToHost);
-            if (FILE* f = std::fopen(log_path, "wb")) { std::fwrite(h.data(), sizeof(uint4), h.size(), f); std::fclose(f); }
+            if (FILE* f = std::fopen(s->knobs.wave_log_path.c_str(), "wb")) { std::fwrite(h.data(), sizeof(uint4), h.size(), f); std::fclose(f); }
             hipFree(wave_log);
         }
+#endif
         if (small_lo >= 0) {
             const int ev = 2 * RT_MAX_LEVELS;
             if (overlap) HIP_TRY(record(ev));
@@ -855,6 +961,13 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
 // An asynchronous frame overflowed: the next ones get 4x the room per sample, by smaller passes while those can shrink,
 // then by a larger pool.
 static void learn_from_overflow(rt_scene* s, uint32_t full_px) {
+    if (s->last_noalloc) {
+        // the frame that overflowed used the static pool: only ITS passes shrink (of RT_NOALLOC_PASS_SAMPLES, down to 64
+        // pixels); the scene's ordinary passes and its hipMalloc'ed pool have nothing to learn from it
+        const uint32_t px = std::max<uint32_t>(64u, RT_NOALLOC_PASS_SAMPLES / std::max<uint32_t>(1u, s->last_spp));
+        if ((px >> s->noalloc_shrink_log2) > 64u) s->noalloc_shrink_log2 = std::min(8u, s->noalloc_shrink_log2 + 2u);
+        return;
+    }
     if ((full_px >> s->shrink_log2) > 64u && s->shrink_log2 < 16) s->shrink_log2 = std::min(16u, s->shrink_log2 + 2u);
     else s->ws_min_n0 = uint32_t(std::min<uint64_t>(RT_POOL_MAX_N0, std::max<uint64_t>(uint64_t(s->ws_n0) * 8u, 65536u)));
 }
@@ -876,13 +989,13 @@ static int render_frame(rt_scene* s, const rt_camera* cam, uint32_t n_frames, co
     // The workspace is sized for the full pass; a scene whose ray trees outgrow the pool (learned from overflows, below
     // and in rt_scene_status) runs smaller passes in the same workspace: 2^k times the room per sample.
     uint32_t full_px = std::max<uint32_t>(64u, RT_PASS_SAMPLES / spp);
-    if (*s->h_overflow && s->last_overflow == -1) { s->last_overflow = 1; learn_from_overflow(s, full_px); }
+    if (*s->h_overflow && s->last_overflow == -1) { s->last_overflow = 1; learn_from_overflow(s, std::max<uint32_t>(64u, RT_PASS_SAMPLES / std::max<uint32_t>(1u, s->last_spp))); }
     uint32_t pass_px = uint32_t(std::min<uint64_t>(total_px, std::max<uint32_t>(64u, full_px >> s->shrink_log2)));
     pass_px = (pass_px + 63u) & ~63u;
     int rc = RT_OK;
     if (noalloc) {
         // whole pixels, a multiple of 64 of them, within the static pool (rounded DOWN; 64 pixels of <= 256 samples fit)
-        const uint32_t fit_px = std::max<uint32_t>(64u, ((RT_NOALLOC_PASS_SAMPLES / spp) >> s->shrink_log2) & ~63u);
+        const uint32_t fit_px = std::max<uint32_t>(64u, ((RT_NOALLOC_PASS_SAMPLES / spp) >> s->noalloc_shrink_log2) & ~63u);
         pass_px = uint32_t(std::min<uint64_t>((total_px + 63u) & ~63ull, fit_px));
         if (uint64_t(pass_px) * spp > RT_NOALLOC_PASS_SAMPLES) { rt_set_error("64 pixels of %u samples do not fit the static workspace", spp); return RT_ERR_LIMIT; }
     } else {
@@ -905,6 +1018,7 @@ static int render_frame(rt_scene* s, const rt_camera* cam, uint32_t n_frames, co
     FrameJob J{};
     J.s = s; J.st = st; J.d_out = d_out; J.timed = stats != nullptr;
     J.progress = sync ? progress : nullptr; J.progress_user = progress_user;
+    J.noalloc = noalloc;
     LevelArgs& B = J.base;
     std::memset(&B, 0, sizeof B);
     B.max_depth = prm->max_depth;
@@ -923,9 +1037,10 @@ static int render_frame(rt_scene* s, const rt_camera* cam, uint32_t n_frames, co
         B.rays = reinterpret_cast<float4*>(w);
         B.sub_cap = s->has_bounce ? (RT_NOALLOC_CAP - RT_NOALLOC_PASS_SAMPLES) / RT_SHARDS : 0u;
     }
-    B.chunk_log2 = RT_SHARD_CHUNK_LOG2;
-    if (const char* e = std::getenv("RT_CHUNK_LOG2")) B.chunk_log2 = std::min<uint32_t>(uint32_t(std::atoi(e)), RT_SHARD_CHUNK_LOG2_MAX);   // experiments
-    if (const char* dbg = std::getenv("RT_DEBUG_SKIP")) { B.debug = uint32_t(std::atoi(dbg)); s->d.debug = B.debug; }   // timing experiments only
+    B.chunk_log2 = uint32_t(s->knobs.chunk_log2);
+#ifdef RT_EXPERIMENTS
+    B.debug = s->knobs.debug; s->d.debug = B.debug;      // timing experiments only (RT_DEBUG_SKIP)
+#endif
     B.aa = s->d_aa;
     B.fp = s->d_fp;
     B.pm = pm;
@@ -938,13 +1053,16 @@ static int render_frame(rt_scene* s, const rt_camera* cam, uint32_t n_frames, co
         if (expect_large(s, 0, lv, lv)) J.large_mask |= 1u << lv;      // (key of the opt-in graph cache only)
 
     const uint64_t n_pass = (total_px + pass_px - 1) / pass_px;
-    if (n_pass > RT_MAX_PASSES) { rt_set_error("frame needs %llu passes (max %d)", (unsigned long long)n_pass, RT_MAX_PASSES); return RT_ERR_LIMIT; }
+    // (an asynchronous frame's passes take the counter slots in turn: enqueue_passes)
+    if (n_pass > RT_MAX_PASSES && sync) { rt_set_error("frame needs %llu passes (max %d)", (unsigned long long)n_pass, RT_MAX_PASSES); return RT_ERR_LIMIT; }
 
     // per-frame inputs: the anti-aliasing pattern (only when it changed) and camera + background
     if (prm->n_aa && (s->aa_cache.size() != size_t(2 * prm->n_aa) ||
                       std::memcmp(s->aa_cache.data(), prm->aa_xy, sizeof(float) * 2 * prm->n_aa) != 0)) {
         s->aa_cache.assign(prm->aa_xy, prm->aa_xy + 2 * prm->n_aa);
-        HIP_TRY(hipMemcpyAsync(s->d_aa, prm->aa_xy, sizeof(float) * 2 * prm->n_aa, hipMemcpyHostToDevice, st));
+        // (as kernel arguments, not a copy: a copy from the caller's pageable memory is staged by the runtime - it may
+        // block and allocate - and a staging buffer of the scene's own could be overwritten while a frame in flight reads it)
+        launch_set_aa(prm->aa_xy, prm->n_aa, s->d_aa, st);
     }
     FrameParamsBatch fp;
     std::memset(&fp, 0, sizeof fp);
@@ -953,6 +1071,7 @@ static int render_frame(rt_scene* s, const rt_camera* cam, uint32_t n_frames, co
         fp.f[b].cam = to_dcamera(cam + b);
     }
     const size_t counter_bytes = sizeof(PassCounters) * std::min<uint64_t>(RT_MAX_PASSES, n_pass * 2 + 16);
+    J.slots_cleared = uint32_t(counter_bytes / sizeof(PassCounters));
     static_assert(sizeof(PassCounters) % 16 == 0, "counters are cleared 16 bytes at a time");
     launch_set_frame_params(fp, n_frames, s->d_fp, s->d_counters, counter_bytes, st);      // also clears the frame's pass counters
     std::vector<PassRec> recs;
@@ -965,7 +1084,8 @@ static int render_frame(rt_scene* s, const rt_camera* cam, uint32_t n_frames, co
         if (s->last_overflow != 1) s->last_overflow = -1;      // unknown until rt_scene_status (1 stays until it is read)
         s->last_stream = st;
         s->last_spp = spp;
-        static const bool no_graph = std::getenv("RT_USE_GRAPH") == nullptr;
+        s->last_noalloc = noalloc;
+        const bool no_graph = !s->knobs.use_graph;
         rt_scene::GraphKey key;
         std::memset(&key, 0, sizeof key);
         key.base = B; key.d_out = d_out; key.total_px = total_px; key.pass_px = pass_px; key.large_mask = J.large_mask;
@@ -1181,7 +1301,7 @@ extern "C" int rt_render(rt_scene* s, const rt_camera* cam, const rt_params* prm
 }
 
 // rt_render that reports how far it is: progress(user, pixels done, pixels of the rectangle) after every pass of the
-// frame (a frame of up to 8 M samples is one pass) and once more, with done == total, when the bytes are in bgr.
+// frame (a frame of up to rt_scene_pass_samples() samples - 2^26 on an MI355X - is one pass) and once more, with done == total, when the bytes are in bgr.
 extern "C" int rt_render_progress(rt_scene* s, const rt_camera* cam, const rt_params* prm, uint32_t x0, uint32_t y0, uint32_t w,
                                   uint32_t h, uint8_t* bgr, rt_stats* stats, rt_progress_fn progress, void* user) {
     if (!s || !bgr) { rt_set_error("null argument"); return RT_ERR_INVALID; }

@@ -30,11 +30,22 @@
 #include "rt_launch.h"
 
 #define RT_EPS 0.000001f   // reference src/common.h:36
+// DScene::debug / LevelArgs::debug switch parts of the kernels off and the wave logs time single waves: timing
+// experiments, built only with -DRT_EXPERIMENTS (make EXTRA=-DRT_EXPERIMENTS). The release build has neither the tests
+// (scalar instructions in the loops whose scalar instructions were counted one by one) nor a way to reach them.
+#ifdef RT_EXPERIMENTS
+#define RT_DBG(x) (x)
+#define RT_LOG_PTR(p) (p)
+#else
+#define RT_DBG(x) 0u
+#define RT_LOG_PTR(p) ((uint4*)nullptr)
+#endif
 #define RT_WIDE_BLOCK_MAX 256
 #ifndef RT_WIDE_BLOCK_DEFAULT
 #define RT_WIDE_BLOCK_DEFAULT 64
 #endif
 #include <cstdlib>
+#include <cstring>
 
 struct V3 { float x, y, z; };
 __device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
@@ -170,6 +181,48 @@ __device__ __forceinline__ bool tri_isect(V3 v0, V3 e1, V3 e2, const Ray& ray, f
     if (v < 0 || u + v > 1) return false;
     t = invDet * dot(qVec, e2);
     return t > RT_EPS;
+}
+
+// The same test for a PACKET (one ray per lane, the triangle wave-uniform): the same operations in the same order, with
+// the reference's two rejections (primitives.cpp:63-64,68-69 and :73-74) as WAVE-UNIFORM exits. Written as tri_isect the
+// compiler flattens the whole test into one block of 63 vector instructions that every visited triangle pays in full;
+// but a packet reaches a leaf when ANY of its rays hits the leaf's box, and most triangles of such a leaf are missed by
+// every ray of the wave: when no lane is left after the `u` test the wave leaves after 36 instructions, after the `v`
+// test after 53. `m` (in: the lanes that take part; out: the lanes whose ray hits, t / u / v valid there) is a lane mask
+// held as a scalar: the ballot of each comparison ANDed on the scalar unit (the ballot of a compound per-lane condition
+// goes through a VGPR and back). Same answer per lane as tri_isect: a lane that failed a rejection keeps computing
+// values that its cleared bit in `m` discards.
+// EXITS: bit 0 = leave after the `u` test, bit 1 = after the `v` test, when no lane is left.
+#ifndef RT_TRI_EXITS_ANY
+#define RT_TRI_EXITS_ANY 3         // shadow packets (A/B builds: 0..3)
+#endif
+#ifndef RT_TRI_MASKS_ANY
+#define RT_TRI_MASKS_ANY 1         // shadow packets: the leaf test on scalar lane masks with wave-uniform exits (0: the flat per-lane form)
+#endif
+#ifndef RT_TRI_MASKS_CLOSEST
+#define RT_TRI_MASKS_CLOSEST 0
+#endif
+#ifndef RT_TRI_PIN_LOADS
+#define RT_TRI_PIN_LOADS 1
+#endif
+#ifndef RT_TRI_EXITS_CLOSEST
+#define RT_TRI_EXITS_CLOSEST 0     // closest-hit packets: the rays of an 8x8-pixel block mostly DO hit the triangles of the leaves they reach
+#endif
+template <int EXITS>
+__device__ __forceinline__ void tri_isect_packet(V3 v0, V3 e1, V3 e2, const Ray& ray, unsigned long long& m, float& t, float& u, float& v) {
+    const V3 pVec = cross(ray.d, e2);
+    const float det = dot(pVec, e1);
+    const float invDet = 1 / det;
+    const V3 tVec = ray.o - v0;
+    u = invDet * dot(pVec, tVec);
+    m &= __builtin_amdgcn_ballot_w64(!(fabsf(det) < RT_EPS)) & __builtin_amdgcn_ballot_w64(!(u < 0)) & __builtin_amdgcn_ballot_w64(!(u > 1));
+    if ((EXITS & 1) && m == 0) return;      // wave-uniform
+    const V3 qVec = cross(tVec, e1);
+    v = invDet * dot(qVec, ray.d);
+    m &= __builtin_amdgcn_ballot_w64(!(v < 0)) & __builtin_amdgcn_ballot_w64(!(u + v > 1));
+    if ((EXITS & 2) && m == 0) return;      // wave-uniform
+    t = invDet * dot(qVec, e2);
+    m &= __builtin_amdgcn_ballot_w64(t > RT_EPS);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -429,15 +482,16 @@ __device__ __forceinline__ void packet_traverse(const DScene& S, uint32_t root, 
     const V3 ood = mk(ray.o.x * inv.x, ray.o.y * inv.y, ray.o.z * inv.z);
     float best = ANY ? tmax : FLT_MAX, bu = 0, bv = 0;
     uint32_t face = 0xFFFFFFFFu;
-    bool live = have;                       // ANY: cleared once the lane's ray is occluded
     int stack = 0;                          // lane k = stack entry k
     uint32_t sp = 0;
-    unsigned long long live_m = __builtin_amdgcn_ballot_w64(have);      // `live` as a scalar (ANY: shrinks at the leaves)
+    bool live = have;                       // (the flat form of the leaf test: a lane's bit of live_m)
+    const unsigned long long have_m = __builtin_amdgcn_ballot_w64(have);
+    unsigned long long live_m = have_m;     // the lanes whose ray is still on its way, a scalar (ANY: a lane leaves once its ray is occluded)
     uint32_t cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)(live_m ? root : RT_DONE));   // RT_NO_CHILD == RT_DONE
     while (cur != RT_DONE) {
         while (!(cur & RT_LEAF_BIT)) {      // (RT_DONE has the leaf bit)
             const RT_CONSTANT u32x4* np = (const RT_CONSTANT u32x4*)(const void*)(S.nodes) + 8u * (size_t)cur;
-            if (COUNT) { wk.nodes += live; wk.wave_nodes += wave_once(); }
+            if (COUNT) { wk.nodes += __builtin_amdgcn_inverse_ballot_w64(live_m); wk.wave_nodes += wave_once(); }
             const float cull = ANY ? best : best * 1.000001f;
             uint32_t key[4], ref[4];
             // the whole node is requested at once (scalar loads return in any order, so the only wait there is is for
@@ -518,7 +572,7 @@ __device__ __forceinline__ void packet_traverse(const DScene& S, uint32_t root, 
         {
             const uint32_t cnt = ((cur >> 27) & 15u) + 1u;
             const RT_CONSTANT u32x4* lp = (const RT_CONSTANT u32x4*)(const void*)(S.leaves) + 12u * (size_t)(cur & RT_LEAF_START_MASK);
-            if (COUNT) { wk.tris += live ? cnt : 0u; wk.wave_tris += wave_once(); }
+            if (COUNT) { wk.tris += __builtin_amdgcn_inverse_ballot_w64(live_m) ? cnt : 0u; wk.wave_tris += wave_once(); }
             // two triangles per request (6 x 16 B, one wait): four requests one after the other are four latencies, the whole
             // block at once (48 SGPRs) makes the kernel spill scalars around the loop - and every spilled SGPR is a VALU
             // instruction (v_writelane / v_readlane), which is what this path is short of
@@ -528,30 +582,47 @@ __device__ __forceinline__ void packet_traverse(const DScene& S, uint32_t root, 
                     u32x4 lf[6];
 #pragma unroll
                     for (int c = 0; c < 3; ++c) { lf[2 * c] = lp[4 * c + t0]; lf[2 * c + 1] = lp[4 * c + t0 + 1]; }
+                    // (both triangles' words are waited for HERE: with exits in the first triangle's test the compiler sinks the
+                    // second triangle's loads below it, and a leaf is four fetch latencies one after the other instead of two)
+                    if (RT_TRI_PIN_LOADS && (ANY ? RT_TRI_MASKS_ANY : RT_TRI_MASKS_CLOSEST)) asm volatile("" :: "s"(lf[1]), "s"(lf[3]), "s"(lf[5]));
 #pragma unroll
                     for (uint32_t dt = 0; dt < 2; ++dt) {
                         if (t0 + dt < cnt) {                                                     // wave-uniform
                             RT_UNIFORM_BRANCH;
                             const float4 q0 = as_f4(lf[dt]), q1 = as_f4(lf[2 + dt]), q2 = as_f4(lf[4 + dt]);
-                            float tt, u, v;
-                            if (live && tri_isect(f4xyz(q0), f4xyz(q1), f4xyz(q2), ray, tt, u, v)) {
-                                const uint32_t f = __float_as_uint(q0.w);
-                                if (ANY) {
-                                    if (tt < tmax) { face = 0; live = false; }
-                                } else if (tt < best || (tt == best && f < face)) {
-                                    best = tt; bu = u; bv = v; face = f;
+                            float tt = 0, u = 0, v = 0;
+                            if (!(ANY ? RT_TRI_MASKS_ANY : RT_TRI_MASKS_CLOSEST)) {      // the flat form: one block per triangle, per-lane conditions
+                                if (live && tri_isect(f4xyz(q0), f4xyz(q1), f4xyz(q2), ray, tt, u, v)) {
+                                    const uint32_t f = __float_as_uint(q0.w);
+                                    if (ANY) {
+                                        if (tt < tmax) live = false;
+                                    } else if (tt < best || (tt == best && f < face)) {
+                                        best = tt; bu = u; bv = v; face = f;
+                                    }
                                 }
+                                continue;
+                            }
+                            unsigned long long m = live_m;      // the lanes whose ray is tested; then: whose ray hits
+                            tri_isect_packet<ANY ? RT_TRI_EXITS_ANY : RT_TRI_EXITS_CLOSEST>(f4xyz(q0), f4xyz(q1), f4xyz(q2), ray, m, tt, u, v);
+                            if (ANY) {      // occluded lanes leave the packet (a scalar mask; `face` is set at the end)
+                                if (m) live_m &= ~(m & __builtin_amdgcn_ballot_w64(tt < tmax));         // wave-uniform
+                            } else {        // (no short-circuit: the three comparisons and four selects, no branches)
+                                const uint32_t f = __float_as_uint(q0.w);
+                                const unsigned long long better = m & (__builtin_amdgcn_ballot_w64(tt < best) |
+                                    (__builtin_amdgcn_ballot_w64(tt == best) & __builtin_amdgcn_ballot_w64(f < face)));
+                                if (__builtin_amdgcn_inverse_ballot_w64(better)) { best = tt; bu = u; bv = v; face = f; }
                             }
                         }
                     }
                 }
             }
-            if (ANY) live_m = __builtin_amdgcn_ballot_w64(live);
+            if (ANY && !RT_TRI_MASKS_ANY) live_m = __builtin_amdgcn_ballot_w64(live);
             if (ANY && live_m == 0) cur = RT_DONE;
             else if (sp) { --sp; cur = (uint32_t)__builtin_amdgcn_readlane(stack, (int)sp); }
             else cur = RT_DONE;
         }
     }
+    if (ANY) face = __builtin_amdgcn_inverse_ballot_w64(have_m & ~live_m) ? 0u : 0xFFFFFFFFu;      // occluded: some face
     out.t = best; out.u = bu; out.v = bv; out.face = face;
 }
 
@@ -607,7 +678,7 @@ __device__ __forceinline__ void serve_traverse(const DScene& S, uint32_t root, b
         }
         next = next + n_idle < n ? next + n_idle : n;
         if (__builtin_amdgcn_ballot_w64(busy) == 0) break;                             // every ray served
-        const uint32_t keep = (S.debug >> 16) ? ((S.debug >> 16) & 31u) : RT_SERVE_KEEP;      // (experiments: RT_DEBUG_SKIP = keep << 16)
+        const uint32_t keep = (RT_DBG(S.debug) >> 16) ? ((RT_DBG(S.debug) >> 16) & 31u) : RT_SERVE_KEEP;      // (experiments: RT_DEBUG_SKIP = keep << 16)
         quad_run<ANY, COUNT>(S, t, qr, qt, qs, next < n ? keep * 4u : 0u, wk);
         if (busy && t.cur == RT_DONE) {
             QuadHit q;
@@ -665,19 +736,19 @@ __device__ __forceinline__ int closest_loop(const DScene& S, const Ray& ray, boo
         if (ob.x == RT_OBJ_SPHERE) {
             RT_UNIFORM_BRANCH;
             if (COUNT) wk.spheres += go && counter;
-            if (go && !(S.debug & 16u)) hit = sphere_isect(prm, __uint_as_float(ob.w), ray, h.tmpdist, tmpnormal, coherent);
+            if (go && !(RT_DBG(S.debug) & 16u)) hit = sphere_isect(prm, __uint_as_float(ob.w), ray, h.tmpdist, tmpnormal, coherent);
         }
         if (ob.x == RT_OBJ_PLANE) {
             RT_UNIFORM_BRANCH;
             if (COUNT) wk.planes += go && counter;
-            if (go && !(S.debug & 16u)) hit = plane_isect(prm, ray, h.tmpdist, tmpnormal);
+            if (go && !(RT_DBG(S.debug) & 16u)) hit = plane_isect(prm, ray, h.tmpdist, tmpnormal);
         }
         if (ob.x != RT_OBJ_SPHERE && ob.x != RT_OBJ_PLANE) {      // (separate tests: see occluded_loop)
             RT_UNIFORM_BRANCH;
             // Model::intersect (reference src/primitives.cpp:364-384): dist = FLT_MAX, bounding-sphere gate, closest
             // face, normal = (1-u-v)*n0 + u*n1 + v*n2 (primitives.cpp:80, not normalised)
             const ModelRef m = load_model(S.models, ob.y);
-            bool need = go && !(S.debug & 8u);
+            bool need = go && !(RT_DBG(S.debug) & 8u);
             if (m.bb.w >= 0) {
                 if (COUNT) wk.spheres += need && counter;
                 need = need && sphere_gate(m.bb, ray, coherent);
@@ -1067,7 +1138,7 @@ __device__ __forceinline__ void extend_finish(const DScene& S, const LevelArgs& 
     r_refl.o = r_refl.d = r_refr.o = r_refr.d = mk(0, 0, 0);
     V3 hitPt = mk(0, 0, 0);
     float rCoef = 0;
-    const int cur = (A.debug & 4u) ? -1 : h.cur;
+    const int cur = (RT_DBG(A.debug) & 4u) ? -1 : h.cur;
     if (valid) {
         rec_b.w = NODE_VALID;
         if (cur >= 0) {
@@ -1260,7 +1331,7 @@ __device__ __forceinline__ void extend_wide_body(const DScene& S, const LevelArg
     const uint32_t next_base_l = v.start + v.cnt;     // lane s: children of shard s are appended behind its level
     Work wk = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (COUNT) { wk.t_start = wall_clock64(); wk.c_start = clock64(); }
-    else if (A.wave_log) wk.t_start = wall_clock64();      // diagnostics (RT_WAVE_LOG): the wave's start and end, nothing else
+    else if (RT_LOG_PTR(A.wave_log)) wk.t_start = wall_clock64();      // diagnostics (RT_WAVE_LOG): the wave's start and end, nothing else
 
     // a workgroup is 1..4 independent waves (RT_WIDE_BLOCK: the dispatcher starts workgroups at a limited rate, and these
     // waves are short-lived), wave w of workgroup b takes groups b * waves + w, ...
@@ -1277,7 +1348,7 @@ __device__ __forceinline__ void extend_wide_body(const DScene& S, const LevelArg
         {   // (camera, pixel map, sample pattern: used once per group, before the traversal)
             const LevelArgs Af = (RT_RELOAD_FOR(PACKET)) ? reload_level_args() : A_;
             valid = active && fetch_ray<SRC>(Af, 0, i, ray);
-            dbg = Af.debug;
+            dbg = RT_DBG(Af.debug);
         }
         HitState h = fresh_hit();
         int susp = -1;
@@ -1302,7 +1373,7 @@ __device__ __forceinline__ void extend_wide_body(const DScene& S, const LevelArg
         if (A.wave_log && lane_id() == 0 && wid < 4u * 8192u)
             A.wave_log[wid] = make_uint4((uint32_t)wk.t_start, (uint32_t)wall_clock64(), steps, (uint32_t)(clock64() - wk.c_start));
         flush_work(A.work, PACKET == 2 ? 2 : 0, wk);
-    } else if (A.wave_log && lane_id() == 0) {
+    } else if (RT_LOG_PTR(A.wave_log) && lane_id() == 0) {
         const uint32_t wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
         if (wid < 4u * 8192u) A.wave_log[wid] = make_uint4((uint32_t)wk.t_start, (uint32_t)wall_clock64(), 0u, 0u);
     }
@@ -1348,7 +1419,7 @@ __device__ __forceinline__ void extend_quad_body(const DScene& S, const LevelArg
 
     const uint32_t R = G.R;
     // Workgroup -> group mapping: see group_of
-    const uint32_t run_log2 = (A.debug >> 8) ? ((A.debug >> 8) & 31u) : RT_RUN_LOG2;
+    const uint32_t run_log2 = (RT_DBG(A.debug) >> 8) ? ((RT_DBG(A.debug) >> 8) & 31u) : RT_RUN_LOG2;
     const uint32_t rl = run_log2 >= 31u ? 0u : run_log2;
     const uint32_t per_cu = ((((G.total + 255u) >> 8) + (1u << rl) - 1u) >> rl) << rl;
     for (uint32_t vb = vblock; vb < (direct ? G.total : per_cu * 256u); vb += vgrid) {
@@ -1387,7 +1458,7 @@ __device__ __forceinline__ void extend_quad_body(const DScene& S, const LevelArg
         if (COUNT) { wk.batches++; }
         unsigned long long c0 = 0;
         if (COUNT) c0 = wall_clock64();
-        if (!(A.debug & 2u)) closest_loop<true, COUNT>(S, ray, valid, k0, h, qs, wk);
+        if (!(RT_DBG(A.debug) & 2u)) closest_loop<true, COUNT>(S, ray, valid, k0, h, qs, wk);
         if (COUNT) wk.trav_ticks += wall_clock64() - c0;
         extend_finish(S, A, i, active, valid, j == 0, ray, h, lane_read(next_base_l, shard), A.n0 + (shard + 1u) * A.sub_cap,
                       A.sc[shard].level + (A.level + 1), FRESH ? 0u : NODE_PARKED);
@@ -1416,7 +1487,7 @@ __device__ __forceinline__ void shade_ray(const DScene& S, const LevelArgs& A_, 
     const float bias = 0.0001f;                                                          // raytracer.cpp:286
     bool red = false;
     parked = -1;
-    const uint32_t dbg = A_.debug;
+    const uint32_t dbg = RT_DBG(A_.debug);
     // the loop runs for the whole wave; `live` says whether this lane is still in ITS light loop
     for (uint32_t li = 0; li < S.n_lights; ++li) {                                       // raytracer.cpp:311-345
         const bool live = hit && !red && parked < 0 && li >= li0;
@@ -1486,7 +1557,7 @@ __device__ __forceinline__ void shade_wide_body(const DScene& S, const LevelArgs
     const Groups G = level0 ? make_groups_dense<false>(A.n0, A.chunk_log2) : make_groups<false>(v.start, v.cnt);
     Work wk = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (COUNT) { wk.t_start = wall_clock64(); wk.c_start = clock64(); }
-    else if (A.wave_log) wk.t_start = wall_clock64();
+    else if (RT_LOG_PTR(A.wave_log)) wk.t_start = wall_clock64();
     uint32_t n_shadow = 0;
     const uint32_t nwv = blockDim.x >> 6;      // see extend_wide_body
     for (uint32_t grp = blockIdx.x * nwv + (threadIdx.x >> 6); grp < G.total; grp += gridDim.x * nwv) {
@@ -1521,7 +1592,7 @@ __device__ __forceinline__ void shade_wide_body(const DScene& S, const LevelArgs
         if (A.wave_log && lane_id() == 0 && wid < 4u * 8192u)
             A.wave_log[wid] = make_uint4((uint32_t)wk.t_start, (uint32_t)wall_clock64(), steps, (uint32_t)(clock64() - wk.c_start));
         flush_work(A.work, PACKET == 2 ? 3 : 1, wk);
-    } else if (A.wave_log && lane_id() == 0) {
+    } else if (RT_LOG_PTR(A.wave_log) && lane_id() == 0) {
         const uint32_t wid = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
         if (wid < 4u * 8192u) A.wave_log[wid] = make_uint4((uint32_t)wk.t_start, (uint32_t)wall_clock64(), 0u, 0u);
     }
@@ -1564,7 +1635,7 @@ __device__ __forceinline__ void shade_quad_body(const DScene& S, const LevelArgs
     uint32_t n_shadow = 0;
     const uint32_t R = G.R;
     // Workgroup -> group mapping: see group_of
-    const uint32_t run_log2 = (A.debug >> 8) ? ((A.debug >> 8) & 31u) : RT_RUN_LOG2;
+    const uint32_t run_log2 = (RT_DBG(A.debug) >> 8) ? ((RT_DBG(A.debug) >> 8) & 31u) : RT_RUN_LOG2;
     const uint32_t rl = run_log2 >= 31u ? 0u : run_log2;
     const uint32_t per_cu = ((((G.total + 255u) >> 8) + (1u << rl) - 1u) >> rl) << rl;
     for (uint32_t vb = vblock; vb < (direct ? G.total : per_cu * 256u); vb += vgrid) {
@@ -1654,6 +1725,15 @@ __global__ __launch_bounds__(256) void k_set_frame_params(FrameParamsChunk p, ui
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n_clear16; i += gridDim.x * 256) clear[i] = make_uint4(0, 0, 0, 0);
 }
 
+// The anti-aliasing pattern by value -> device memory (when it changed): as kernel arguments it needs no copy from the
+// caller's pageable memory and no staging buffer that a frame in flight might still read.
+struct AAPattern { float xy[2 * RT_MAX_AA_POINTS]; };
+static_assert(sizeof(AAPattern) <= 2048, "the pattern travels in the kernel-argument segment");
+__global__ __launch_bounds__(256) void k_set_aa(AAPattern p, uint32_t n_floats, float* dst) {
+    const RT_CONSTANT float* words = (const RT_CONSTANT float*)__builtin_amdgcn_kernarg_segment_ptr();   // p is the first argument
+    for (uint32_t i = threadIdx.x; i < n_floats; i += 256) dst[i] = words[i];
+}
+
 // Fold of one level (>= 1): finishes every node whose children were traced one level deeper. Wave vwave of vwaves.
 __device__ __forceinline__ void fold_body(const DScene& S, const LevelArgs& A, uint32_t vwave, uint32_t vwaves) {
     const ShardView v = shard_view(A, A.level, A.level);
@@ -1741,7 +1821,7 @@ __global__ __launch_bounds__(64 * RT_TAIL_WG_WAVES) __attribute__((amdgpu_waves_
         const uint32_t vb = blockIdx.x * RT_TAIL_WG_WAVES + wave, vg = n_e * RT_TAIL_WG_WAVES;
         uint32_t phase = 0;
         // diagnostics (RT_TAIL_LOG): workgroup 0 and the last E workgroup log {phase start, work done, barrier passed} in 10-ns ticks
-        uint4* log = (A.wave_log && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == n_e - 1)) ? A.wave_log + (blockIdx.x ? 64 : 0) : nullptr;
+        uint4* log = (RT_LOG_PTR(A.wave_log) && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == n_e - 1)) ? A.wave_log + (blockIdx.x ? 64 : 0) : nullptr;
         for (int lv = lv_first; lv <= lv_last; ++lv) {
             const unsigned long long t0 = log ? wall_clock64() : 0ull;
             A.level = lv; A.level_hi = lv;
@@ -2122,6 +2202,12 @@ void launch_set_frame_params(const FrameParamsBatch& p, uint32_t n_frames, Frame
         for (uint32_t i = n; i < RT_FP_CHUNK; ++i) c.f[i] = p.f[f0];
         hipLaunchKernelGGL(k_set_frame_params, dim3(f0 ? 1u : grid), dim3(256), 0, st, c, n, dst + f0, static_cast<uint4*>(clear), f0 ? 0u : n16);
     }
+}
+void launch_set_aa(const float* aa_xy, uint32_t n_points, float* dst, hipStream_t st) {
+    AAPattern p;
+    std::memset(&p, 0, sizeof p);
+    std::memcpy(p.xy, aa_xy, sizeof(float) * 2 * std::min<uint32_t>(n_points, RT_MAX_AA_POINTS));
+    hipLaunchKernelGGL(k_set_aa, dim3(1), dim3(256), 0, st, p, 2u * std::min<uint32_t>(n_points, RT_MAX_AA_POINTS), dst);
 }
 void launch_tail(const DScene& S, const LevelArgs& A, int lv_first, int lv_last, uint32_t* bar, uint32_t workgroups, hipStream_t st) {
     if (S.generic_pow) hipLaunchKernelGGL((k_tail<true>), dim3(workgroups), dim3(64 * RT_TAIL_WG_WAVES), 0, st, S, A, lv_first, lv_last, bar);

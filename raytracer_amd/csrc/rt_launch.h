@@ -158,6 +158,7 @@ enum { RT_FORM_WIDE = 0, RT_FORM_QUAD_FRESH = 1, RT_FORM_QUAD_RESUME = 2, RT_FOR
 void launch_extend(int src, int form, bool count, const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st);
 void launch_shade(int form, bool count, const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st);
 void launch_set_frame_params(const FrameParamsBatch& p, uint32_t n_frames, FrameParams* dst, void* clear, size_t clear_bytes, hipStream_t st);   // clear: 16-byte multiple
+void launch_set_aa(const float* aa_xy, uint32_t n_points, float* dst, hipStream_t st);      // host pattern -> device, as kernel arguments
 void launch_fold(const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st);
 // levels lv_first..lv_last (>= 1) in one launch of `workgroups` (even, at most RT_TAIL_MAX_WG: all resident at once)
 // small workgroups: closest hits, light loops, folds (k_tail). bar: 3 words, zero at the start of the launch

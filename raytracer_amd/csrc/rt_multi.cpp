@@ -182,26 +182,41 @@ extern "C" int rt_multi_render_device(rt_multi* m, const rt_camera* cam, const r
     if (stats) std::memset(stats, 0, sizeof *stats);
     const uint32_t slot_tiles = uint32_t(m->part_bytes / (size_t(t) * t * 3));
     hipStream_t s0 = static_cast<hipStream_t>(rt_scene_stream(m->scenes[0]));
+    // A failure after some parts were enqueued must not leave half a frame behind: the parts already on their way are
+    // waited for (their status is dropped: the call fails anyway) and the cross-device event state starts afresh, so the
+    // next frame neither waits for an ev_gathered that was never recorded for it nor reads an ev_rendered of this one.
+    auto abandon = [&](int code) {
+        char keep[512];
+        std::snprintf(keep, sizeof keep, "%s", rt_last_error());
+        for (uint32_t p = 0; p < n; ++p) (void)rt_scene_status(m->scenes[p]);
+        m->gathered_once = false;
+        rt_set_error("%s", keep);
+        return code;
+    };
     for (uint32_t q = 0; q < n; ++q) {
-        MULTI_TRY(hipSetDevice(m->devices[q]));
+        if (hipSetDevice(m->devices[q]) != hipSuccess) { rt_set_error("hipSetDevice(%d) failed", m->devices[q]); (void)hipGetLastError(); return abandon(RT_ERR_DEVICE); }
         hipStream_t sq = static_cast<hipStream_t>(rt_scene_stream(m->scenes[q]));
         // part q's buffer is free again once the previous frame's copies have read it
-        if (q > 0 && m->gathered_once) MULTI_TRY(hipStreamWaitEvent(sq, m->ev_gathered, 0));
+        if (q > 0 && m->gathered_once && hipStreamWaitEvent(sq, m->ev_gathered, 0) != hipSuccess) { rt_set_error("hipStreamWaitEvent failed"); (void)hipGetLastError(); return abandon(RT_ERR_DEVICE); }
         rt_stats ps;
         rc = rt_render_tiles_device(m->scenes[q], cam, prm, t, t, q, n, m->d_tiles[q], nullptr, stats ? &ps : nullptr);
-        if (rc != RT_OK) return rc;
+        if (rc != RT_OK) return abandon(rc);
         if (stats) add_stats(stats, ps);
-        if (q > 0) MULTI_TRY(hipEventRecord(m->ev_rendered[q], sq));
+        if (q > 0 && hipEventRecord(m->ev_rendered[q], sq) != hipSuccess) { rt_set_error("hipEventRecord failed"); (void)hipGetLastError(); return abandon(RT_ERR_DEVICE); }
     }
-    MULTI_TRY(hipSetDevice(m->devices[0]));
+#define MULTI_TRY_ABANDON(expr) do { if ((expr) != hipSuccess) { rt_set_error("%s failed (%s:%d)", #expr, __FILE__, __LINE__); (void)hipGetLastError(); return abandon(RT_ERR_DEVICE); } } while (0)
+    MULTI_TRY_ABANDON(hipSetDevice(m->devices[0]));
     for (uint32_t q = 1; q < n; ++q) {
         const size_t bytes = size_t(rt_tiles_owned(cam->imWidth, cam->imHeight, t, t, q, n)) * t * t * 3;
-        MULTI_TRY(hipStreamWaitEvent(s0, m->ev_rendered[q], 0));
+        MULTI_TRY_ABANDON(hipStreamWaitEvent(s0, m->ev_rendered[q], 0));
         uint8_t* dst = m->d_all + size_t(q) * m->part_bytes;
-        if (m->devices[q] == m->devices[0]) MULTI_TRY(hipMemcpyAsync(dst, m->d_tiles[q], bytes, hipMemcpyDeviceToDevice, s0));
-        else MULTI_TRY(hipMemcpyPeerAsync(dst, m->devices[0], m->d_tiles[q], m->devices[q], bytes, s0));
+        // (the branch between DIFFERENT devices - hipMemcpyPeerAsync, the cross-device wait above - has not run yet:
+        // every box this was developed on had one GPU; INTEGRATION.md says so)
+        if (m->devices[q] == m->devices[0]) MULTI_TRY_ABANDON(hipMemcpyAsync(dst, m->d_tiles[q], bytes, hipMemcpyDeviceToDevice, s0));
+        else MULTI_TRY_ABANDON(hipMemcpyPeerAsync(dst, m->devices[0], m->d_tiles[q], m->devices[q], bytes, s0));
     }
-    if (n > 1) { MULTI_TRY(hipEventRecord(m->ev_gathered, s0)); m->gathered_once = true; }
+    if (n > 1) { MULTI_TRY_ABANDON(hipEventRecord(m->ev_gathered, s0)); m->gathered_once = true; }
+#undef MULTI_TRY_ABANDON
     return rt_untile_device(m->devices[0], cam->imWidth, cam->imHeight, t, t, n, slot_tiles, m->d_all, d_bgr_out, s0);
 }
 

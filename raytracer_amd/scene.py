@@ -538,6 +538,10 @@ class DeviceScene:
         """rt_scene_set_pass_samples: level-0 samples per pass (power of two in [2^12, 2^26]; 0 = default)."""
         cabi.check(self.lib, self.lib.rt_scene_set_pass_samples(self.h, int(samples)))
 
+    def set_option(self, name, value):
+        """rt_scene_set_option: fix one choice of the launch schedule (tests, experiments); results never depend on it."""
+        cabi.check(self.lib, self.lib.rt_scene_set_option(self.h, name.encode(), int(value)))
+
     def bvh_info(self):
         info = cabi.rt_bvh_info()
         cabi.check(self.lib, self.lib.rt_scene_bvh_info(self.h, C.byref(info)))

@@ -51,7 +51,7 @@ def test_frames_golden(name):
         got, _ = dev.render(cam, p)
         d = np.abs(got.astype(np.int16) - g[key].astype(np.int16)).max(axis=2)
         worst = min(worst, float((d <= 1).mean()))
-        assert (d <= 1).mean() >= 0.999, key
+        assert (d <= 1).mean() >= 0.999 and (d == 0).mean() >= 0.9999, key      # north_star's bar; what is measured: every pixel equal
     print(f"{name}: worst within-1-LSB share over 5 frames {worst:.6f}")
     if name != "mesh":
         got, st = dev.render(camera_from_array(g["cam_large"]), Params())
@@ -88,9 +88,8 @@ def test_tiles_on_one_gpu_equal_the_full_frame():
 def test_index_arithmetic_paths_agree():
     """Sample index -> frame / pixel / tile: where a pass' indices fit 32 bits the kernels divide by reciprocal
     multiplication (udivmod32), else by the 64-bit expansion (frames beyond 2^32 samples, too large to test).
-    RT_NO_FAST32 forces the latter: full frame at 3 samples per pixel (a divisor that is not a power of two), a
+    Option "index64" (rt_scene_set_option) forces the latter: full frame at 3 samples per pixel (a divisor that is not a power of two), a
     rectangle, tiles in 3 parts and a batch of 3 frames give the same bytes both ways."""
-    import os
     import torch
     fs = wl.scene_bunny(10, third="glass2")
     cam = reference_camera(400, 296)
@@ -99,31 +98,21 @@ def test_index_arithmetic_paths_agree():
     p = Params(max_depth=3, aa=((0.5, 0.5), (0.25, 0.75)))
     W, H = cam.imWidth, cam.imHeight
     got = {}
-    saved = os.environ.get("RT_NO_FAST32")
-    try:
-        for mode in ("fast", "wide"):
-            if mode == "wide":
-                os.environ["RT_NO_FAST32"] = "1"            # read at every pass
-            else:
-                os.environ.pop("RT_NO_FAST32", None)
-            dev = DeviceScene(fs)
-            full, st = dev.render(cam, p)
-            rect, _ = dev.render(cam, p, rect=(37, 21, 203, 150))
-            slot = dev.lib.rt_tiles_owned(W, H, 32, 32, 0, 3)
-            allt = torch.zeros((3, slot * 32 * 32 * 3), dtype=torch.uint8, device="cuda")
-            batch = torch.zeros((3, H, W, 3), dtype=torch.uint8, device="cuda")
-            torch.cuda.synchronize()
-            for part in range(3):
-                dev.render_tiles_device(cam, p, (32, 32), part, 3, allt[part].data_ptr())
-            dev.render_batch_device(cams, p, batch.data_ptr(), H * W * 3)
-            dev.status()
-            torch.cuda.synchronize()
-            got[mode] = (full, st.trace_calls, rect, allt.cpu().numpy(), batch.cpu().numpy())
-    finally:
-        if saved is None:
-            os.environ.pop("RT_NO_FAST32", None)
-        else:
-            os.environ["RT_NO_FAST32"] = saved
+    for mode in ("fast", "wide"):
+        dev = DeviceScene(fs)
+        dev.set_option("index64", 1 if mode == "wide" else 0)
+        full, st = dev.render(cam, p)
+        rect, _ = dev.render(cam, p, rect=(37, 21, 203, 150))
+        slot = dev.lib.rt_tiles_owned(W, H, 32, 32, 0, 3)
+        allt = torch.zeros((3, slot * 32 * 32 * 3), dtype=torch.uint8, device="cuda")
+        batch = torch.zeros((3, H, W, 3), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        for part in range(3):
+            dev.render_tiles_device(cam, p, (32, 32), part, 3, allt[part].data_ptr())
+        dev.render_batch_device(cams, p, batch.data_ptr(), H * W * 3)
+        dev.status()
+        torch.cuda.synchronize()
+        got[mode] = (full, st.trace_calls, rect, allt.cpu().numpy(), batch.cpu().numpy())
     a, b = got["fast"], got["wide"]
     assert a[1] == b[1]
     for k in (0, 2, 3, 4):
@@ -174,11 +163,11 @@ def _oracle_pixels(O, fs, cam, p, pixels):
 # workload -> how the oracle checks it: ("frame",) the whole frame; ("rects", [...]) crops through orc_render;
 # ("pixels", [...]) single pixels through orc_trace. Sized to a few CPU-seconds each.
 FULL_SIZE = {
-    "bunny_1080p": ("rects", [(700, 0, 2, 1080)]),                       # a strip through the mesh and the mirror sphere
+    "bunny_1080p": ("rects", [(692, 0, 16, 1080), (1100, 300, 16, 480)]),  # strips through the mesh and the mirror sphere; through the glass sphere
     "c2_analytic_1080p_4spp": ("frame",),
-    "c3_bunny_1080p_shadows": ("rects", [(700, 0, 2, 1080)]),
+    "c3_bunny_1080p_shadows": ("rects", [(692, 0, 16, 1080)]),
     "c4_bunny_glass_4k_16spp": ("rects", [(1088, 272, 48, 32), (1580, 1390, 32, 32)]),     # in the glass2 sphere; on the mesh
-    "c5_field_10m_8k_64spp": ("pixels", [(3840, 2721), (2560, 3456), (5000, 3000), (3000, 2400), (4400, 3900), (1200, 2900)]),  # on the blobs of the field
+    "c5_field_10m_8k_64spp": ("pixels", [(3840, 2721), (2560, 3456), (5000, 3000), (3000, 2400), (4400, 3900), (1200, 2900), (3846, 2727), (2553, 3449)]),  # on the blobs of the field
 }
 
 
@@ -231,7 +220,7 @@ def test_full_size_properties(workload):
         d = np.abs(got.astype(np.int16) - want.astype(np.int16)).max(axis=1)
     print(f"{workload}: {st.trace_calls}+{st.shadow_rays} rays, {st.passes} passes; oracle sample of {d.size} px: "
           f"within 1 LSB {(d <= 1).mean():.6f}, equal {(d == 0).mean():.6f}")
-    assert (d <= 1).mean() >= 0.999
+    assert (d <= 1).mean() >= 0.999 and (d == 0).mean() >= 0.9999
 
 
 @pytest.mark.parametrize("spp_grid", [1, 2])
@@ -261,7 +250,7 @@ def test_many_passes_equal_one_pass(spp_grid):
     want, so = O.Oracle(fs).render(cam, p, threads=16)
     d = np.abs(many.astype(np.int16) - want.astype(np.int16)).max(axis=2)
     assert so.trace_calls == st2.trace_calls and so.shadow_rays == st2.shadow_rays
-    assert (d <= 1).mean() >= 0.999
+    assert (d <= 1).mean() >= 0.999 and (d == 0).mean() >= 0.9999
     with pytest.raises(cabi.RtError):
         dev.set_pass_samples(5000)                                        # not a power of two
     dev.set_pass_samples(0)

@@ -285,7 +285,8 @@ def test_frame_parity(oracle_mod, case):
     within1, equal, worst = frame_stats(got, want)
     print(f"{case}: within 1 LSB {within1:.6f}, equal {equal:.6f}, worst {worst}, rays {st1.trace_calls}+{st1.shadow_rays}")
     assert st1.trace_calls == st2.trace_calls and st1.shadow_rays == st2.shadow_rays
-    assert within1 >= 0.999
+    assert within1 >= 0.999           # the north_star bar
+    assert equal >= 0.9999            # what is measured: every pixel equal
     if case == "analytic_1spp":   # SURVEY.md §8c known answer of the reference itself
         assert st1.trace_calls == 534339 and st1.shadow_rays == 1068678
         assert abs(int(got.astype(np.int64).sum()) - 42340267) <= 0.001 * got.size
@@ -322,7 +323,7 @@ def test_random_spheres_frames(oracle_mod, seed):
     print(f"seed {seed}: within 1 LSB {within1:.6f}, equal {equal:.6f}, worst {worst}, rays {st1.trace_calls}+{st1.shadow_rays}")
     assert st1.trace_calls == st2.trace_calls and st1.shadow_rays == st2.shadow_rays
     assert list(st1.level_rays) == list(st2.level_rays)
-    assert within1 >= 0.9999
+    assert within1 >= 0.9999 and equal >= 0.9999
 
 
 def test_schedule_forms_agree(oracle_mod):
@@ -345,47 +346,38 @@ def test_schedule_forms_agree(oracle_mod):
     assert np.array_equal(frame.cpu().numpy(), a)
     want, st_o = oracle_mod.Oracle(fs).render(cam, p)
     within1, equal, worst = frame_stats(a, want)
-    assert within1 >= 0.999
+    assert within1 >= 0.999 and equal >= 0.9999
     assert st_a.trace_calls == st_o.trace_calls and st_a.shadow_rays == st_o.shadow_rays
 
 
 @pytest.mark.parametrize("spp_grid", [1, 4])
 def test_traversal_forms_agree(spp_grid):
     """Every way the library can take a frame through a mesh gives the same bytes and ray counts: level 0 by marks +
-    quads (RT_PACKET=0), as 64-ray packets (1), packets at the deeper levels too (2); bounce levels as per-lane kernels
-    + queues + resuming quads (RT_LARGE_THR=0: every level "large"), as one quad launch per level (huge threshold), or
-    as per-lane kernels whose quads serve the rays that reach the mesh (RT_SERVE=1); the deep levels one launch each
-    (RT_TAIL=0) or all of them - closest hits, light loops, folds - in one single-workgroup launch (k_tail: from level 1
-    on with a huge threshold, from where the levels hold <= 300 rays with RT_TAIL=300).
+    quads (option "packet" 0, rt_scene_set_option), as 64-ray packets (1), packets at the deeper levels too (2); bounce
+    levels as per-lane kernels + queues + resuming quads ("large_threshold" 0: every level "large"), as one quad launch
+    per level (huge threshold), or as per-lane kernels whose quads serve the rays that reach the mesh ("serve" 1); the
+    deep levels one launch each ("tail_rays" 0) or all of them - closest hits, light loops, folds - in one launch
+    (k_tail: from level 1 on with a huge threshold, from where the levels hold <= 300 rays with 300).
     The defaults pick among these by samples per pixel and level size; test_frame_parity pins the default to the
     oracle."""
-    import os
     fs = wl.scene_bunny(10, third="glass2")
     cam, p = reference_camera(320, 240), Params(max_depth=6, aa=wl.aa_grid(spp_grid) if spp_grid > 1 else ())
-    saved = {k: os.environ.get(k) for k in ("RT_PACKET", "RT_LARGE_THR", "RT_SERVE", "RT_SPLIT_SMALL", "RT_TAIL")}
     frames = {}
-    try:
-        for packet, thr, serve, split, tail in (
-                ("0", "0", "0", "1", "0"), ("0", "1000000000", "0", "1", "0"), ("1", "0", "0", "1", "0"),
-                ("1", "1000000000", "0", "1", "0"), ("1", "1000000000", "1", "1", "0"), ("1", "1000000000", "0", "0", "0"),
-                ("2", "0", "0", "1", "0"), ("2", "1000000000", "0", "1", "0"),
-                ("1", "1000000000", "0", "1", "1000000000"), ("1", "1000000000", "0", "1", "300"),
-                ("1", "1000000000", "1", "1", "300"), ("0", "0", "0", "1", "300"), ("2", "0", "0", "1", "300")):
-            os.environ["RT_PACKET"] = packet            # read when the scene is created
-            os.environ["RT_TAIL"] = tail                # read at every call: levels of at most this many rays go to k_tail
-            os.environ["RT_LARGE_THR"] = thr            # read at every call
-            os.environ["RT_SERVE"] = serve              # bounce levels one ray per lane with quad service / one ray per quad
-            os.environ["RT_SPLIT_SMALL"] = split        # small levels shaded per lane + resuming quads / one quad launch per run
-            dev = DeviceScene(fs)
-            dev.render(cam, p)                          # (the second frame of a scene knows its level sizes)
-            img, st = dev.render(cam, p)
-            frames[(packet, thr, serve, split, tail)] = (img, st.trace_calls, st.shadow_rays, list(st.level_rays))
-    finally:
-        for k, v in saved.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+    for packet, thr, serve, split, tail in (
+            ("0", "0", "0", "1", "0"), ("0", "1000000000", "0", "1", "0"), ("1", "0", "0", "1", "0"),
+            ("1", "1000000000", "0", "1", "0"), ("1", "1000000000", "1", "1", "0"), ("1", "1000000000", "0", "0", "0"),
+            ("2", "0", "0", "1", "0"), ("2", "1000000000", "0", "1", "0"),
+            ("1", "1000000000", "0", "1", "1000000000"), ("1", "1000000000", "0", "1", "300"),
+            ("1", "1000000000", "1", "1", "300"), ("0", "0", "0", "1", "300"), ("2", "0", "0", "1", "300")):
+        dev = DeviceScene(fs)
+        dev.set_option("packet", int(packet))            # how level 0 (1) / every large level (2) goes through the mesh
+        dev.set_option("tail_rays", int(tail))           # levels of at most this many rays go to k_tail
+        dev.set_option("large_threshold", int(thr))      # rays from which a bounce level is "large"
+        dev.set_option("serve", int(serve))              # bounce levels one ray per lane with quad service / one ray per quad
+        dev.set_option("split_small", int(split))        # small levels shaded per lane + resuming quads / one quad launch per run
+        dev.render(cam, p)                               # (the second frame of a scene knows its level sizes)
+        img, st = dev.render(cam, p)
+        frames[(packet, thr, serve, split, tail)] = (img, st.trace_calls, st.shadow_rays, list(st.level_rays))
     base = frames[("1", "1000000000", "0", "1", "0")]
     for key, f in frames.items():
         assert np.array_equal(f[0], base[0]), key
@@ -432,7 +424,7 @@ def test_scanned_like_ply_frames(oracle_mod, tmp_path):
     want, st2 = orc.render(cam, p)
     within1, equal, worst = frame_stats(got, want)
     assert (st1.trace_calls, st1.shadow_rays) == (st2.trace_calls, st2.shadow_rays)
-    assert within1 >= 0.999, (within1, equal, worst)
+    assert within1 >= 0.999 and equal >= 0.9999, (within1, equal, worst)
     rays = np.concatenate([camera_rays(oracle_mod, cam, Params(), 1), edge_rays(fs, 300, 3)])
     h2, d2, n2 = orc.intersect(rays, -1)
     hit = h2 >= 0
@@ -500,7 +492,7 @@ def test_pool_overflow_is_rerun_in_smaller_passes(oracle_mod):
           f"within 1 LSB {within1:.6f}")
     assert st1.retries > 0 and st1.passes > 1
     assert st1.trace_calls == st2.trace_calls and st1.shadow_rays == st2.shadow_rays
-    assert within1 >= 0.999
+    assert within1 >= 0.999 and equal >= 0.9999
     # the scene remembers: the same frame again needs no retry
     again, st3 = dev.render(cam, p)
     assert st3.retries == 0 and np.array_equal(again, got)

@@ -12,19 +12,26 @@ from raytracer_amd.scene import DeviceScene, Params, reference_camera
 pytestmark = pytest.mark.gpu
 
 
-def _frame(dev, cam, p, rect, noalloc):
+def _frame(dev, cam, p, rect, noalloc, attempts=None):
     """One asynchronous frame into a device buffer, by the documented protocol: rt_scene_status reports a frame whose
-    ray trees outgrew the pool (the scene then uses smaller passes) and the caller renders it again."""
+    ray trees outgrew the pool (the scene then uses smaller passes) and the caller renders it again. The no-alloc call
+    must leave the device's free memory as it found it (hipMemGetInfo, through torch)."""
     import torch
     buf = torch.zeros((cam.imHeight, cam.imWidth, 3), dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()                 # the scene's stream is not ordered against torch's fill
     for attempt in range(10):
         if noalloc:
+            free0 = torch.cuda.mem_get_info()[0]
             dev.render_device_noalloc(cam, p, buf.data_ptr(), rect=rect)
+            assert torch.cuda.mem_get_info()[0] == free0, "rt_render_device_noalloc changed the device's free memory"
         else:
             dev.render_device(cam, p, buf.data_ptr(), rect=rect)
         try:
             dev.status()                     # waits
+            if noalloc:
+                assert torch.cuda.mem_get_info()[0] == free0
+            if attempts is not None:
+                attempts.append(attempt)
             return buf.cpu().numpy()
         except cabi.RtError as e:
             assert "pool" in str(e)
@@ -66,3 +73,22 @@ def test_noalloc_rejects_sizes_above_its_maximum():
     p1 = Params()
     want = _frame(dev, cam, p1, None, False)
     assert np.array_equal(_frame(dev, cam, p1, None, True), want)
+
+
+def test_noalloc_overflows_at_its_maximum_size():
+    """The largest frame the entry point takes (1920x1080 at 1 sample per pixel) on a scene whose ray trees outgrow the
+    static pool twice over: every overflow quarters the NO-ALLOC passes only (2^14 -> 2^12 -> 2^10 samples: 2025 passes,
+    more than the scene's 1024 pass-counter slots, which an asynchronous frame takes in turn), the frame then equals the
+    ordinary call's, and the scene's ordinary passes are what they were."""
+    from test_gpu_parity import hall_of_mirrors
+    fs = hall_of_mirrors()
+    cam, p = reference_camera(1920, 1080), Params(max_depth=8)
+    dev = DeviceScene(fs)
+    want = _frame(dev, cam, p, None, False)
+    ordinary = dev.pass_samples()
+    tries = []
+    got = _frame(dev, cam, p, None, True, attempts=tries)
+    assert tries[0] >= 2, tries              # reported (and learned from) at least twice
+    assert np.array_equal(got, want)
+    assert dev.pass_samples() == ordinary
+    assert np.array_equal(_frame(dev, cam, p, None, False), want)      # the ordinary path still renders as before
