@@ -75,6 +75,12 @@ def parse_args():
     ap.add_argument("--rehearse-launcher", action="store_true",
                     help="rehearsal only (no GPU needed): the ranks rendezvous, all-gather their ranks and rank 0 prints "
                          "what it saw; checks that --gpus N really is N processes")
+    ap.add_argument("--ply", default=None,
+                    help="a mesh file (ASCII .ply, e.g. the Stanford bun_zipper.ply the reference's scene.yaml:98-104 names) in place "
+                         "of the procedural blob wherever the workload's scene holds scene.yaml's mesh object")
+    ap.add_argument("--scene", default=None,
+                    help="a scene file in the reference's schema (src/scene.cpp:32-178) in place of the workload's scene; frame "
+                         "size, samples per pixel and depth stay the workload's")
     ap.add_argument("--watchdog", type=int, default=0, help="dump all Python stacks and exit after this many seconds")
     return ap.parse_args()
 
@@ -221,7 +227,7 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
-    fs, cam, params = wl.make_workload(args.workload)
+    fs, cam, params = wl.make_workload(args.workload, ply=args.ply, scene_file=args.scene)
     t0 = time.time()
     dev = DeviceScene(fs, device=local, bvh=args.bvh)
     build_s = time.time() - t0
@@ -286,16 +292,25 @@ def main():
         torch.cuda.synchronize()
     rays_per_frame = st.trace_calls + st.shadow_rays       # of the reference camera
 
-    def step(i, b=1):
-        """Call number i: the next b (<= B) frames, on slot i % slots."""
+    def step(i, b=1, marks=None):
+        """Call number i: the next b (<= B) frames, on slot i % slots. marks (a list): events on the slot's stream before
+        the render, after it, after the gather and after the untile (the untimed phase diagnostics of an N-rank run)."""
         sl = slots[i % len(slots)]
         sl.last_b = b
         h = sl.stream.cuda_stream
+
+        def mark():
+            if marks is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record(sl.stream)
+                marks.append(e)
         with torch.cuda.stream(sl.stream):
             if not multi:
                 sl.dev.render_batch_device(cams[:b], params, sl.frames.data_ptr(), frame_bytes, stream=h)
                 return
+            mark()
             sl.dev.render_tiles_batch_device(cams[:b], params, (tw, th), rank, world, sl.mine.data_ptr(), sl.part_bytes, stream=h)
+            mark()
             if "gather" in os.environ.get("BENCH_SKIP", ""):     # diagnostics: time the path without its exchange / untile
                 pass
             elif args.backend == "nccl":
@@ -308,9 +323,14 @@ def main():
                 if rank == 0:
                     sl.allt.copy_(torch.cat(hg))
             if rank == 0 and "untile" not in os.environ.get("BENCH_SKIP", ""):       # part q's tiles of frame k start at tile slot q * B * n_slot + k * n_slot; one launch
+                mark()
                 cabi.check(lib, lib.rt_untile_batch_device(local, W, H, tw, th, world, B * sl.n_slot, b, sl.part_bytes,
                                                            frame_bytes, C.c_void_p(sl.allt.data_ptr()),
                                                            C.c_void_p(sl.frames.data_ptr()), C.c_void_p(h)))
+                mark()
+            else:
+                mark()
+                mark()
 
     def run_steps(n):
         """n frames as ceil(n / B) calls; returns the rays of those frames (rank 0 knows them)."""
@@ -358,8 +378,31 @@ def main():
     if overflowed():
         raise SystemExit("bench.py: a timed frame ran out of ray pool; the measurement is void")
     rccl_ranks = 1
+    phases = None
     if multi:
         rccl_ranks = dist.get_world_size()
+        # Where an N-rank frame's time goes (untimed, after the measurement): ONE call at a time, events on the slot's stream
+        # around the rank's render, the gather and rank 0's untile; per frame, max and mean over the ranks. With calls in
+        # flight the phases of one call overlap those of the other, so these sum to more than ms_per_step.
+        per = [0.0, 0.0, 0.0]
+        n_diag = 4
+        for k in range(n_diag):
+            marks = []
+            step(k, B, marks)
+            sync()
+            for j in range(3):
+                per[j] += marks[j].elapsed_time(marks[j + 1]) / (B * n_diag)
+        mine = torch.tensor(per + [float(lib.rt_tiles_owned(W, H, tw, th, rank, world))], dtype=torch.float64,
+                            device="cuda" if args.backend == "nccl" else "cpu")
+        allp = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allp, mine)
+        allp = torch.stack(allp).cpu()
+        phases = {name: {"max": float(allp[:, j].max()), "mean": float(allp[:, j].mean())}
+                  for j, name in enumerate(("render_ms", "gather_ms", "untile_ms"))}
+        phases["untile_ms"] = {"rank0": float(allp[0, 2])}
+        phases["tiles_per_rank"] = [int(x) for x in allp[:, 3]]
+        phases["note"] = ("per frame, one call at a time (no overlap between calls): render = this rank's tiles, gather = the "
+                          "exchange to rank 0 as the rank's stream sees it (a peer's includes waiting for rank 0), untile on rank 0")
         if "barrier" not in os.environ.get("BENCH_SKIP", ""):
             e = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
             dist.all_reduce(e, op=dist.ReduceOp.MAX)
@@ -379,7 +422,8 @@ def main():
                        "trace_calls": st.trace_calls, "shadow_rays": st.shadow_rays,
                        "level_rays": [int(x) for x in st.level_rays[:params.c.max_depth + 1]],
                        "parallelism": "1 GPU" if world == 1 else f"{world} GPUs: {tw}x{th} tiles round-robin, RCCL gather",
-                       "mesh": "procedural geodesic blob (no .ply ships with the reference)",
+                       "mesh": (f"scene file {args.scene}" if args.scene else f"{args.ply} (--ply)" if args.ply else
+                                "procedural geodesic blob (no .ply ships with the reference)"),
                        "scene_build_s": round(build_s, 3), "bvh": args.bvh,
                        "bvh_build_s": round(dev.bvh_info().build_seconds, 4),
                        "cameras": "reference camera" if args.same_camera else
@@ -388,6 +432,8 @@ def main():
         }
         identical = all(bool(torch.equal(sl.frames[k], ref_frames[k])) for sl in slots for k in range(sl.last_b))
         out["frame_identical_to_1gpu"] = identical
+        if phases is not None:
+            out["phases"] = phases
         out["config"]["frames_in_flight"] = len(slots)
         out["config"]["frames_per_batch"] = B
         out["config"]["pool_adapt_rounds"] = adapt_rounds
@@ -486,9 +532,9 @@ def extras(args, out, dev, slots, fs, cam, cams, params, st, rays_per_frame, cam
     per_kernel = {names[k]: {"avg_launch_ms": ms[k] / n[k], "launches_per_frame": n[k] / reps, "ms_per_frame_serial": ms[k] / reps}
                   for k in range(NK) if n[k]}
 
-    # ---- roofline of the dominant LAUNCH. A frame at max_depth 0 runs exactly the level-0 launches (the heaviest of
-    # the frame), one per kernel: HIP-event durations, work counters and PMC counters there belong to single launches,
-    # which rocprofv3 lists under the same templated names. ----
+    # ---- roofline of the dominant LAUNCH. A frame at max_depth 0 runs exactly the level-0 launches
+    # (the heaviest of the frame): one per kernel and PASS, so HIP-event durations, work counters and PMC counters there
+    # belong to single launches, which rocprofv3 lists under the same templated names. ----
     p0 = Params(background=tuple(params.c.background), max_depth=0, aa=params.aa)
     ms0, n0, _ = timed_frames(p0, reps)
     # per-RAY algorithmic work (the nodes / triangles each ray's OWN traversal visits): the same depth-0
@@ -499,11 +545,15 @@ def extras(args, out, dev, slots, fs, cam, cams, params, st, rays_per_frame, cam
     devq.render_device(cam, p0, frame.data_ptr(), stats=s0)
     wq = [devq.get_work(k) for k in range(NK)]
     devq.close()
-    # what the packets do instead: node / triangle steps per WAVE (one scalar fetch serves 64 rays)
+    # what the packets do instead - node / triangle steps per WAVE (one scalar fetch serves 64 rays) - and the clock the
+    # launch runs at: the counting instantiation of the same kernels stamps s_memtime (shader cycles) and s_memrealtime
+    # (100 MHz) at the start and the end of every wave (MI355X_MICROARCH.md: clock = d s_memtime / d s_memrealtime x 100 MHz)
     dev.set_count_work(True)
-    sp = rt_stats()
-    dev.render_device(cam, p0, frame.data_ptr(), stream=stream, stats=sp)
-    wp = [dev.get_work(k) for k in range(NK)]
+    wp = None
+    for _ in range(3):
+        sp = rt_stats()
+        dev.render_device(cam, p0, frame.data_ptr(), stream=stream, stats=sp)
+        wp = [dev.get_work(k) for k in range(NK)]
     dev.set_count_work(False)
     dev.render_device(cam, params, frame.data_ptr(), stream=stream)      # leave the full frame in the buffer
     dev.status()
@@ -519,62 +569,102 @@ def extras(args, out, dev, slots, fs, cam, cams, params, st, rays_per_frame, cam
                      "k_shade_quad<1, false, false>", "k_shade_quad<2, false, false>")
     dk = max(range(2), key=lambda k: ms0[k] / max(n0[k], 1))      # level 0 = the two per-lane launches
     avg_ms = ms0[dk] / n0[dk]
+    launches = n0[dk] / reps                                       # per depth-0 frame = its passes
     rays_k = s0.trace_calls if dk == 0 else s0.shadow_rays
     hits = s0.shadow_rays // max(len(fs.lights), 1)
-    b_alg, f_alg = algorithmic_work(per_ray[dk], rays_k, hits if dk == 1 else 0, len(fs.lights))
-    # PMC counters of the same launch, collected by tools/collect_counters.sh (bench.py cannot run rocprofv3 on itself)
-    ctr_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"counters_{args.workload}.json")))
-    ctr, ctr_src = None, None
+    b_frame, f_frame = algorithmic_work(per_ray[dk], rays_k, hits if dk == 1 else 0, len(fs.lights))
+    b_alg, f_alg = b_frame / launches, f_frame / launches         # the census is of the whole frame: ONE launch is a pass of it
+    clock_mhz = 100.0 * wp[dk].wave_cycles_sum / max(wp[dk].wave_ticks_sum, 1)
+    if not 500.0 < clock_mhz < 3000.0:
+        clock_mhz = None
+    peak_tfl = VALU_PEAK_TFLOPS * (clock_mhz / (CLOCK_GHZ * 1e3)) if clock_mhz else VALU_PEAK_TFLOPS
+    alg_tfl = f_alg / (avg_ms * 1e-3) / 1e12
+    alg_gbs = b_alg / (avg_ms * 1e-3) / 1e9
+    # PMC counters of the same launch, collected by tools/collect_counters.sh (bench.py cannot run rocprofv3 on itself):
+    # newest round first, and only if they were collected from THESE kernels (hash of sources + flags)
+    from raytracer_amd.buildinfo import kernels_hash
+    def round_of(path):
+        try:
+            return int(os.path.basename(os.path.dirname(path))[1:])
+        except ValueError:
+            return -1
+    ctr_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"counters_{args.workload}.json")), key=round_of)
+    ctr, ctr_src, stale = None, None, None
     if ctr_files:
         cj = json.load(open(ctr_files[-1]))
+        stale = cj.get("kernels_hash") != kernels_hash()
         ctr = cj.get("depth0", {}).get(rocprof_names[dk])
         if ctr:      # a frame of several passes launches the kernel once per pass: counters per LAUNCH
             nl = max(ctr.get("launches", 1.0), 1.0)
             ctr = {k: v / nl for k, v in ctr.items()}
-        ctr_src = {"file": os.path.relpath(ctr_files[-1], ROOT), "commit": cj.get("commit"), "kernel": rocprof_names[dk],
-                   "note": "counters come from this committed file, durations and work counts are measured live"}
-    roof = {"kernel": rocprof_names[dk], "avg_launch_ms": avg_ms, "launches_per_frame_at_depth0": n0[dk] / reps,
-            "units_per_launch": dict(per_ray[dk], rays=rays_k,
-                                     note="per RAY: each ray traversed by itself (RT_SCENE_NO_PACKETS census of the same frame)"),
-            "packet_steps_per_launch": {"wave_node_steps": wp[dk].wave_node_steps, "wave_tri_steps": wp[dk].wave_tri_steps,
-                                        "lane_node_visits": wp[dk].nodes_visited, "lane_tri_tests": wp[dk].tris_tested,
+        ctr_src = {"file": os.path.relpath(ctr_files[-1], ROOT), "commit": cj.get("commit"), "kernels_hash": cj.get("kernels_hash"),
+                   "kernels_hash_now": kernels_hash(), "kernel": rocprof_names[dk],
+                   "note": "counters come from this committed file (tools/collect_counters.sh), durations, work counts and the "
+                           "clock are measured live; stale = the kernels or their build flags changed since it was collected"}
+    fresh = ctr if (ctr and not stale) else None
+    traffic = fresh["hbm_bytes"] if fresh else None
+    roof = {"kernel": rocprof_names[dk], "bound": "valu_fp32",
+            "achieved": alg_tfl, "peak": peak_tfl, "unit": "TFLOP/s", "frac": alg_tfl / peak_tfl, "traffic": traffic,
+            "definition": "achieved = SURVEY.md 8(d) flops/ray x the per-ray census of ONE launch / that launch's average duration "
+                          "(HIP events on the scene's stream); peak = 1024 SIMDs x 32 lanes x 2 flop x the shader clock measured in "
+                          "the launch (157.3 TFLOP/s at the 2400 MHz of MI355X_MICROARCH.md; no MFMA on this path: nothing is a "
+                          "dense contraction); traffic = HBM bytes per launch from the PMC counters (2 x FETCH_SIZE + WRITE_SIZE)",
+            "shader_clock_mhz": clock_mhz, "peak_at_2400_mhz": VALU_PEAK_TFLOPS, "frac_of_peak_at_2400_mhz": alg_tfl / VALU_PEAK_TFLOPS,
+            "avg_launch_ms": avg_ms, "launches_per_frame_at_depth0": launches,
+            "units_per_launch": dict({k: v / launches for k, v in per_ray[dk].items()}, rays=rays_k / launches,
+                                     note="per RAY: each ray traversed by itself (RT_SCENE_NO_PACKETS census of the same frame), "
+                                          "divided by the frame's launches of this kernel (one per pass)"),
+            "packet_steps_per_launch": {"wave_node_steps": wp[dk].wave_node_steps / launches, "wave_tri_steps": wp[dk].wave_tri_steps / launches,
+                                        "lane_node_visits": wp[dk].nodes_visited / launches, "lane_tri_tests": wp[dk].tris_tested / launches,
                                         "note": "what the launch executes: one scalar fetch and one step per WAVE for its 64 rays"},
+            "algorithmic": {"flops_per_launch": f_alg, "TFLOP/s": alg_tfl, "bytes_per_launch": b_alg, "GB/s": alg_gbs,
+                            "note": "SURVEY.md 8(d) formulas x per-ray counts / launches / launch duration. The bytes are served by "
+                                    "L2 and the scalar cache (nodes, leaves, object table: see traffic), so their rate is not an HBM "
+                                    "rate and is not priced against the HBM peak"},
             "level0_launch_ms": {rocprof_names[k]: ms0[k] / n0[k] for k in range(NK) if n0[k]},
-            "serial_frame_ms": frame_ms / reps, "kernels": per_kernel, "counters_from": ctr_src}
-    alg_gbs = b_alg / (avg_ms * 1e-3) / 1e9
-    alg_tfl = f_alg / (avg_ms * 1e-3) / 1e12
-    roof["algorithmic"] = {"bytes_per_launch": b_alg, "GB/s": alg_gbs, "of_hbm_peak": alg_gbs / HBM_PEAK_GBS,
-                           "flops_per_launch": f_alg, "TFLOP/s": alg_tfl, "of_valu_peak": alg_tfl / VALU_PEAK_TFLOPS,
-                           "note": "SURVEY.md 8(d) formulas x per-ray counts / launch duration. Nodes, leaves and the object "
-                                   "table are served by L2 and the scalar cache (see traffic), so the byte rate is not an HBM rate"}
-    traffic = ctr["hbm_bytes"] if ctr else None
-    hbm_heavy = traffic is not None and traffic / (avg_ms * 1e-3) / 1e9 > 0.4 * HBM_PEAK_GBS
-    if ctr and not hbm_heavy:
-        # what binds a launch whose working set lives in L2: instruction issue
-        ginst = ctr["SQ_INSTS_VALU"] / (avg_ms * 1e-3) / 1e9
-        roof.update({"bound": "valu_issue", "achieved": ginst, "peak": VALU_ISSUE_PEAK_GINST, "unit": "G wave64-instructions/s",
-                     "frac": ginst / VALU_ISSUE_PEAK_GINST, "traffic": traffic,
-                     "valu_instructions_per_launch": ctr["SQ_INSTS_VALU"], "salu_instructions_per_launch": ctr.get("SQ_INSTS_SALU"),
-                     "valu_pipe_busy_4cycle": ctr["SQ_INSTS_VALU"] * 4 / (SIMDS * CLOCK_GHZ * 1e9 * avg_ms * 1e-3),
-                     "wait_inst_share_of_wave_cycles": ctr.get("SQ_WAIT_INST_ANY", 0) / max(ctr.get("SQ_WAVE_CYCLES", 1), 1),
-                     "wait_any_share_of_wave_cycles": ctr.get("SQ_WAIT_ANY", 0) / max(ctr.get("SQ_WAVE_CYCLES", 1), 1),
-                     "l2_hit_rate": ctr.get("TCC_HIT_sum", 0) / max(ctr.get("TCC_HIT_sum", 0) + ctr.get("TCC_MISS_sum", 0), 1),
-                     "note": "peak = 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (SIMD-32; equals the 157.3 TFLOP/s "
-                             "FMA peak); valu_pipe_busy_4cycle prices every instruction at 4 cycles, which is what min/max/"
-                             "compare/select/DPP/readlane cost on this chip (tools/valu_rate.hip)"})
-    elif ctr:
+            "serial_frame_ms": frame_ms / reps, "kernels": per_kernel, "counters_from": ctr_src, "counters_stale": stale}
+    if fresh:
+        clk = (clock_mhz or CLOCK_GHZ * 1e3) * 1e6
+        ginst = fresh["SQ_INSTS_VALU"] / (avg_ms * 1e-3) / 1e9
+        wc = max(fresh.get("SQ_WAVE_CYCLES", 1), 1)
         rate = traffic / (avg_ms * 1e-3) / 1e9
-        roof.update({"bound": "hbm", "achieved": rate, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rate / HBM_PEAK_GBS,
-                     "traffic": traffic, "note": "achieved = measured HBM bytes (2 x FETCH_SIZE + WRITE_SIZE) / launch duration"})
-    else:
-        # no counter file for this workload: the algorithmic byte rate, capped by what the formula can mean
-        roof.update({"bound": "hbm", "achieved": alg_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": min(alg_gbs / HBM_PEAK_GBS, 1.0), "traffic": None,
-                     "note": "no profiles/r*/counters_<workload>.json: algorithmic bytes only; frac is capped at 1 because "
-                             "cache-served bytes can exceed what HBM could deliver"})
-    if ctr:
-        roof["hbm_measured"] = {"bytes_per_launch": traffic, "GB/s": traffic / (avg_ms * 1e-3) / 1e9,
-                                "of_hbm_peak": traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        roof["valu_issue"] = {
+            "valu_instructions_per_launch": fresh["SQ_INSTS_VALU"], "salu_instructions_per_launch": fresh.get("SQ_INSTS_SALU"),
+            "G_wave64_instructions_per_s": ginst, "peak_G_per_s": SIMDS * clk / 2.0 / 1e9, "utilisation": ginst / (SIMDS * clk / 2.0 / 1e9),
+            "lane_ops_per_algorithmic_flop": fresh["SQ_INSTS_VALU"] * 64.0 / f_alg,
+            "wait_inst_share_of_wave_cycles": fresh.get("SQ_WAIT_INST_ANY", 0) / wc,
+            "wait_any_share_of_wave_cycles": fresh.get("SQ_WAIT_ANY", 0) / wc,
+            "l2_hit_rate": fresh.get("TCC_HIT_sum", 0) / max(fresh.get("TCC_HIT_sum", 0) + fresh.get("TCC_MISS_sum", 0), 1),
+            "note": "EXECUTED wave64 VALU instructions / duration against one per 2 cycles per SIMD at the measured clock: how busy "
+                    "the issue slots are, overhead included - a diagnostic, not the roofline fraction"}
+        roof["hbm_measured"] = {"bytes_per_launch": traffic, "GB/s": rate, "of_hbm_peak": rate / HBM_PEAK_GBS,
+                                "x_algorithmic_bytes": traffic / b_alg}
+    # ---- the same launch in the BATCHED configuration `value` is measured in: a timed call (HIP events around every launch,
+    # one stream) of B frames at max_depth 0 = the level-0 launches of a batch. Its rays are the cameras' census rays. ----
+    if len(cams) > 1 and cam_rays:
+        sb = rt_stats()
+        dev.render_batch_device(cams, p0, slots[0].frames.data_ptr(), frame_bytes, stream=stream, stats=sb)
+        dev.render_batch_device(cams, p0, slots[0].frames.data_ptr(), frame_bytes, stream=stream, stats=sb)
+        if sb.kernel_launches_by[dk]:
+            ms_b = sb.kernel_ms_by[dk] / sb.kernel_launches_by[dk]
+            scale = (sum(cam_rays) / cam_rays[0]) / sb.kernel_launches_by[dk]      # rays of the batch per launch, in frames of camera 0
+            tfl_b = f_frame * scale / (ms_b * 1e-3) / 1e12
+            roof["batched_launch"] = {"frames_per_call": len(cams), "launches": sb.kernel_launches_by[dk], "avg_launch_ms": ms_b,
+                                      "ms_per_frame": sb.kernel_ms_by[dk] / len(cams), "TFLOP/s": tfl_b, "frac": tfl_b / peak_tfl,
+                                      "note": "the dominant kernel's launch when a call carries a batch of frames (what `value` times): "
+                                              "algorithmic flops of camera 0's census x the batch's rays / camera 0's rays"}
+        # ... and every kernel kind of a whole batched call (full depth), launches back to back on one stream
+        sf = rt_stats()
+        dev.render_batch_device(cams, params, slots[0].frames.data_ptr(), frame_bytes, stream=stream, stats=sf)
+        dev.render_batch_device(cams, params, slots[0].frames.data_ptr(), frame_bytes, stream=stream, stats=sf)
+        roof["batched_call_serial"] = {"frames_per_call": len(cams), "ms_per_frame": sf.kernel_ms / len(cams),
+                                       "ms_per_frame_by_kernel": {names[k]: sf.kernel_ms_by[k] / len(cams) for k in range(NK) if sf.kernel_launches_by[k]},
+                                       "launches_by_kernel": {names[k]: sf.kernel_launches_by[k] for k in range(NK) if sf.kernel_launches_by[k]},
+                                       "note": "one call of B frames with HIP events around every launch (one stream, nothing overlaps); "
+                                               "k_extend_quad / k_shade_quad rows include the quad-service launches of the bounce levels; "
+                                               "the remainder of ms_per_frame is folds, resolve and frame set-up"}
+        dev.render_batch_device(cams[:1], params, slots[0].frames.data_ptr(), frame_bytes, stream=stream)
+        dev.status()
     out["roofline"] = roof
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(fs, cam, params, dev, np)

@@ -405,6 +405,8 @@ typedef struct rt_work {
     uint64_t trav_waves;        /* waves that ran at least one batch                               */
     uint64_t wave_ticks_sum;    /* 10-ns ticks between a wave's start and its end, summed          */
     uint64_t wave_ticks_max;    /* ... the longest-lived wave                                      */
+    uint64_t wave_cycles_sum;   /* shader cycles (s_memtime) between a wave's start and its end, summed: the clock the launch
+                                   ran at = wave_cycles_sum / wave_ticks_sum x 100 MHz                */
 } rt_work;
 int rt_set_count_work(rt_scene* scene, int enable);
 int rt_get_work(const rt_scene* scene, int kernel, rt_work* out);

@@ -95,7 +95,8 @@ class rt_work(C.Structure):
                 ("spheres_tested", C.c_uint64), ("planes_tested", C.c_uint64),
                 ("wave_node_steps", C.c_uint64), ("wave_tri_steps", C.c_uint64),
                 ("trav_ticks_sum", C.c_uint64), ("trav_ticks_max", C.c_uint64), ("batches", C.c_uint64),
-                ("trav_waves", C.c_uint64), ("wave_ticks_sum", C.c_uint64), ("wave_ticks_max", C.c_uint64)]
+                ("trav_waves", C.c_uint64), ("wave_ticks_sum", C.c_uint64), ("wave_ticks_max", C.c_uint64),
+                ("wave_cycles_sum", C.c_uint64)]
 
 
 def fptr(a):

@@ -51,7 +51,7 @@ struct PassCounters {                 // one per pass, zeroed by one memset per 
     uint32_t overflow;
     uint32_t tail_bar[3];                // k_tail: arrivals of its two roles, abort flag
     unsigned long long shadow[RT_STAT_SHARDS];
-    unsigned long long work[RT_WORK_SHARDS][RT_N_KINDS][12];   // per shard: RT_K_* kernels
+    unsigned long long work[RT_WORK_SHARDS][RT_N_KINDS][RT_WORK_WORDS];   // per shard: RT_K_* kernels
     uint32_t appended(int lv) const { uint32_t n = 0; for (uint32_t k = 0; k < RT_SHARDS; ++k) n += sc[k].level[lv]; return n; }
 };
 
@@ -513,6 +513,7 @@ static void add_work(rt_work& w, const unsigned long long* c) {
     w.trav_ticks_sum += c[6]; w.trav_ticks_max = std::max<uint64_t>(w.trav_ticks_max, c[7]);
     w.batches += c[8]; w.trav_waves += c[9];
     w.wave_ticks_sum += c[10]; w.wave_ticks_max = std::max<uint64_t>(w.wave_ticks_max, c[11]);
+    w.wave_cycles_sum += c[12];
 }
 extern "C" int rt_get_work(const rt_scene* s, int kernel, rt_work* out) {
     if (!s || !out || kernel < -1 || kernel >= RT_N_KINDS) { rt_set_error("bad argument"); return RT_ERR_INVALID; }
@@ -525,6 +526,7 @@ extern "C" int rt_get_work(const rt_scene* s, int kernel, rt_work* out) {
         out->trav_ticks_sum += a.trav_ticks_sum; out->trav_ticks_max = std::max(out->trav_ticks_max, a.trav_ticks_max);
         out->batches += a.batches; out->trav_waves += a.trav_waves;
         out->wave_ticks_sum += a.wave_ticks_sum; out->wave_ticks_max = std::max(out->wave_ticks_max, a.wave_ticks_max);
+        out->wave_cycles_sum += a.wave_cycles_sum;
     }
     return RT_OK;
 }

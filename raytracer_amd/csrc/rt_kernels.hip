@@ -1064,11 +1064,12 @@ __device__ __forceinline__ bool pick_marked(unsigned long long mask, uint32_t po
 }
 
 __device__ __forceinline__ void flush_work(unsigned long long* work, uint32_t kernel, const Work& wk) {
-    unsigned long long* out = work + ((blockIdx.x & (RT_WORK_SHARDS - 1)) * RT_N_KINDS + kernel) * 12;   // sharded like shadow_count
+    unsigned long long* out = work + ((blockIdx.x & (RT_WORK_SHARDS - 1)) * RT_N_KINDS + kernel) * RT_WORK_WORDS;   // sharded like shadow_count
     const uint32_t a = wave_sum(wk.nodes), b = wave_sum(wk.tris), c = wave_sum(wk.spheres), d = wave_sum(wk.planes);
     const uint32_t e = wave_sum(wk.wave_nodes), f = wave_sum(wk.wave_tris);
     if (lane_id() == 0) {
         const unsigned long long life = wall_clock64() - wk.t_start;
+        atomicAdd(out + 12, (unsigned long long)(clock64() - wk.c_start));      // shader cycles of the same span: the clock this launch ran at
         atomicAdd(out + 6, wk.trav_ticks);
         atomicMax(out + 7, wk.trav_ticks);
         atomicAdd(out + 8, (unsigned long long)wk.batches);

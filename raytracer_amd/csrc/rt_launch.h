@@ -8,7 +8,8 @@
 #define RT_BLOCK 64          // one wave per workgroup: waves retire independently, no barrier is ever needed
 #define RT_MAX_LEVELS 16     // recursion levels 0..max_depth, max_depth <= 15
 #define RT_N_KINDS 5          // k_extend_wide, k_shade_wide, k_extend_quad, k_shade_quad<0|1>, k_shade_quad<2>
-#define RT_WORK_SHARDS 64      // COUNT builds: [shard][kind][12] words
+#define RT_WORK_SHARDS 64      // COUNT builds: [shard][kind][RT_WORK_WORDS] words
+#define RT_WORK_WORDS 14
 #define RT_STAT_SHARDS 256    // statistics atomics are spread over this many words: one word saturates at ~90 atomics/us
 
 // Scene in HBM (SoA). All pointers are device pointers owned by rt_scene.
@@ -106,7 +107,7 @@ struct LevelArgs {
     uint32_t* overflow;          // set to 1 if a child did not fit
     uint32_t* host_overflow;     // pinned host word: k_resolve raises it when the pass overflowed (asynchronous frames)
     unsigned long long* shadow_count;   // [RT_STAT_SHARDS], indexed by workgroup
-    unsigned long long* work;    // [RT_WORK_SHARDS][RT_N_KINDS][12] traversal work counters (COUNT builds only)
+    unsigned long long* work;    // [RT_WORK_SHARDS][RT_N_KINDS][RT_WORK_WORDS] traversal work counters (COUNT builds only)
     float4* rays;                // 2 per pool entry >= n0: origin, direction
     float4* node_a;              // per pool entry: r g b rCoef
     uint4* node_b;               // per pool entry: refl child, refr child, material, flags

@@ -63,6 +63,7 @@ def add_yaml_planes(fs, mats):
 
 
 _mesh_cache = {}
+PLY_OVERRIDE = None      # bench.py --ply: a supplied mesh file (the reference's scene.yaml:103 names bun_zipper_res2.ply) instead of the blob
 
 
 def yaml_mesh(n_subdiv, seed=2, cache_dir=None):
@@ -70,6 +71,12 @@ def yaml_mesh(n_subdiv, seed=2, cache_dir=None):
     procedural 20*n*n-face blob in place of bun_zipper*.ply, taken through the PLY loader + transform chain of
     the C++ host surface exactly as the reference's loader would."""
     key = (n_subdiv, seed)
+    if PLY_OVERRIDE:      # the same loader and transform chain, on the caller's file
+        key = ("ply", PLY_OVERRIDE)
+        if key not in _mesh_cache:
+            _mesh_cache[key] = Mesh.load_ply(PLY_OVERRIDE, rotation=(0.0, 0.5235987755982988, 0.0), scale=20.0,
+                                             translation=(-1.5, -1.0, -6.0))
+        return _mesh_cache[key]
     if key in _mesh_cache:
         return _mesh_cache[key]
     d = cache_dir or tempfile.gettempdir()
@@ -178,6 +185,18 @@ def orbit_cameras(width, height, n, radius=0.05):
     return cams
 
 
-def make_workload(name):
+def make_workload(name, ply=None, scene_file=None):
+    """ply: a .ply to use wherever the workload's scene holds scene.yaml's mesh object (its transform chain applied);
+    scene_file: a scene file in the reference's schema (src/scene.cpp:32-178) in place of the workload's scene - frame
+    size, samples per pixel and depth stay the workload's, the camera is the reference's."""
+    global PLY_OVERRIDE
     factory, W, H, aa, depth = WORKLOADS[name]
-    return factory(), reference_camera(W, H), Params(max_depth=depth, aa=aa)
+    if scene_file:
+        fs = FlatScene.load_yaml(scene_file)
+    else:
+        PLY_OVERRIDE = os.path.abspath(ply) if ply else None
+        try:
+            fs = factory()
+        finally:
+            PLY_OVERRIDE = None
+    return fs, reference_camera(W, H), Params(max_depth=depth, aa=aa)

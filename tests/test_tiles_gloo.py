@@ -104,3 +104,7 @@ def test_bench_two_ranks_on_one_gpu():
     assert r.returncode == 0, r.stderr[-2000:]
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["frame_identical_to_1gpu"] is True
     assert d["value"] > 0 and d["config"]["parallelism"].startswith("2 GPUs")
+    # where an N-rank frame's time goes: per-phase times (max / mean over the ranks) and the tiles each rank owns
+    ph = d["phases"]
+    assert ph["render_ms"]["max"] >= ph["render_ms"]["mean"] > 0 and ph["gather_ms"]["max"] > 0 and ph["untile_ms"]["rank0"] > 0
+    assert len(ph["tiles_per_rank"]) == 2 and sum(ph["tiles_per_rank"]) == 25 * 19      # 800x600 in 32x32 tiles

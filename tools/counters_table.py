@@ -71,7 +71,10 @@ for w in res:
     for k, v in res[w].items():
         v["hbm_bytes"] = 2.0 * 1024.0 * v.get("FETCH_SIZE", 0.0) + 1024.0 * v.get("WRITE_SIZE", 0.0)
 stamp = os.path.join(os.path.dirname(os.path.abspath(__file__)), ".commit_stamp")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from raytracer_amd.buildinfo import kernels_hash  # noqa: E402
 out = {"workload": W, "commit": open(stamp).read().strip() if os.path.exists(stamp) else "unknown",
+       "kernels_hash": kernels_hash(),      # of the kernel sources + build flags these counters were collected from
        "collected_by": "tools/collect_counters.sh (rocprofv3 --pmc, one pass per counter group; --kernel-trace for trace_ns)",
        "note": "depth0 = the frame at max_depth 0 (one launch per kernel: per-launch numbers); frame = one full frame; "
                "hbm_bytes = 2*FETCH_SIZE + WRITE_SIZE in bytes",
