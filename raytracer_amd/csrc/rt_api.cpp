@@ -49,7 +49,8 @@ struct PassCounters {                 // one per pass, zeroed by one memset per 
     ShardCounters sc[RT_SHARDS];         // per shard: entries appended / queued per level
     uint32_t cancel[RT_MAX_LEVELS + 4];  // per level: children of parents that took trace()'s `return red` exit
     uint32_t overflow;
-    uint32_t tail_bar[3];                // k_tail: arrivals of its two roles, abort flag
+    uint32_t tail_levels[RT_MAX_LEVELS + 4];   // k_tail: entries per TRUE level (it counts them all in sc[].level[root + 1])
+    uint32_t pad_[3];
     unsigned long long shadow[RT_STAT_SHARDS];
     unsigned long long work[RT_WORK_SHARDS][RT_N_KINDS][RT_WORK_WORDS];   // per shard: RT_K_* kernels
     uint32_t appended(int lv) const { uint32_t n = 0; for (uint32_t k = 0; k < RT_SHARDS; ++k) n += sc[k].level[lv]; return n; }
@@ -87,8 +88,7 @@ struct Knobs {
     int serve = -1;               // RT_SERVE: bounce levels by quad service: 0 never, 1 always, -1 by pass size
     int split_small = 1;          // RT_SPLIT_SMALL: runs of small levels shaded per lane + resuming quads (1) / one quad launch (0)
     int tiny_run = 1024;          // RT_TINY_RUN: a run of at most this many hits is one quad launch
-    long long tail = 0;           // RT_TAIL: levels of at most this many rays go to k_tail (0: never)
-    int tail_wg = RT_TAIL_MAX_WG; // RT_TAIL_WG
+    long long tail = 8192;        // RT_TAIL: the levels that, with everything deeper, hold at most this many rays go to k_tail (0: never)
     int index64 = 0;              // RT_NO_FAST32: sample index arithmetic by 64-bit division even where 32 bits would do
     int chunk_log2 = RT_SHARD_CHUNK_LOG2;   // RT_CHUNK_LOG2
     int use_graph = 0;            // RT_USE_GRAPH: replay asynchronous frames as a hipGraph (measured slower)
@@ -99,7 +99,7 @@ struct Knobs {
     uint32_t debug = 0;           // RT_DEBUG_SKIP: parts of the kernels switched off (timing experiments; WRONG frames)
     int wave_log_level = -1;      // RT_WAVE_LOG=<level>:<file>
     bool wave_log_shade = false;  // RT_WAVE_LOG_SHADE
-    std::string wave_log_path, tail_log_path;   // RT_TAIL_LOG=<file>
+    std::string wave_log_path;
 #endif
 };
 static long long env_ll(const char* name, long long dflt) { const char* e = std::getenv(name); return e ? std::atoll(e) : dflt; }
@@ -112,7 +112,6 @@ static Knobs knobs_from_env() {
     k.split_small = int(env_ll("RT_SPLIT_SMALL", k.split_small));
     k.tiny_run = int(std::max(0ll, env_ll("RT_TINY_RUN", k.tiny_run)));
     k.tail = std::max(0ll, env_ll("RT_TAIL", k.tail));
-    k.tail_wg = int(std::min<long long>(RT_TAIL_MAX_WG, std::max(2ll, env_ll("RT_TAIL_WG", k.tail_wg)))) & ~1;
     k.index64 = std::getenv("RT_NO_FAST32") ? 1 : 0;
     k.chunk_log2 = int(std::min<long long>(RT_SHARD_CHUNK_LOG2_MAX, std::max(0ll, env_ll("RT_CHUNK_LOG2", k.chunk_log2))));
     k.use_graph = std::getenv("RT_USE_GRAPH") ? 1 : 0;
@@ -126,7 +125,6 @@ static Knobs knobs_from_env() {
         if (const char* c = std::strchr(e, ':')) k.wave_log_path = c + 1; else k.wave_log_level = -1;
     }
     k.wave_log_shade = std::getenv("RT_WAVE_LOG_SHADE") != nullptr;
-    if (const char* e = std::getenv("RT_TAIL_LOG")) k.tail_log_path = e;
 #endif
     return k;
 }
@@ -467,7 +465,6 @@ extern "C" int rt_scene_set_option(rt_scene* s, const char* name, int64_t value)
     else if (n == "split_small") k.split_small = value ? 1 : 0;
     else if (n == "tiny_run") k.tiny_run = int(std::max<int64_t>(0, std::min<int64_t>(value, 1 << 30)));
     else if (n == "tail_rays") k.tail = std::max<int64_t>(0, value);
-    else if (n == "tail_workgroups") k.tail_wg = int(std::min<int64_t>(RT_TAIL_MAX_WG, std::max<int64_t>(2, value))) & ~1;
     else if (n == "index64") k.index64 = value ? 1 : 0;
     else if (n == "chunk_log2") k.chunk_log2 = int(std::min<int64_t>(RT_SHARD_CHUNK_LOG2_MAX, std::max<int64_t>(0, value)));
     else if (n == "graph") k.use_graph = value ? 1 : 0;
@@ -756,6 +753,7 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
         // a shade stream waits for an event once per RECORDING of it: slots are re-recorded within a pass (ev_sync[2*lv]
         // before shade_small and again after that level's per-lane extend), so the elision compares (slot, generation)
         int last_wait[3] = {-1, -1, -1};
+        int small_runs = 0;      // runs of small levels shaded so far in this pass
         int ev_gen[2 * RT_MAX_LEVELS + 5] = {};
         auto record = [&](int slot) -> hipError_t { ++ev_gen[slot]; return hipEventRecord(s->ev_sync[slot], sa); };
         // (a "lean" schedule for small passes - one shade stream, one shade launch for all small levels, deep levels folded
@@ -774,7 +772,9 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
 #endif
         // shade launch `form` over levels lo..hi on the level's shade stream, after event `after` of stream A
         auto shade = [&](int form, int lo, int hi, int after, bool small_run = false) -> int {
-            const int which = ((form == RT_FORM_QUAD_FRESH || small_run) ? 2 : (lo & 1)) % s->n_shade_streams;
+            // (runs of small levels take the third stream and the second in turn: the run that ends a pass - the tail's hits -
+            // would otherwise queue behind the resumed shadow rays of the run before it, 45 us of a one-frame call)
+            const int which = ((form == RT_FORM_QUAD_FRESH || small_run) ? 2 - (small_runs & 1) : (lo & 1)) % s->n_shade_streams;
             hipStream_t sb = overlap ? s->shade_stream[which] : sa;
             if (overlap) {
                 const int stamp = after * 65536 + ev_gen[after];
@@ -812,7 +812,7 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
         // scene at 2^26 32.0 -> 31.0 ms, at 2^25 34.1 -> 33.1; 10 M-triangle field at 8K: 2^23 632 -> 673 ms, 2^26 the same.)
         const bool serve = s->d.packet >= 1 && (serve_env >= 0 ? serve_env != 0 : (A.n0 >= (s->d.packet == 1 ? (4u << 20) : (32u << 20))));
         const bool split_small = s->knobs.split_small != 0;
-        auto shade_small = [&](int lo, int hi, int after) -> int {
+        auto shade_small_run = [&](int lo, int hi, int after) -> int {
             // (not where the per-lane kernels traverse meshes as packets at every level: the rays of a small bounce level
             // have nothing in common - 10 M-triangle field at 8K 64 spp 717 -> 970 ms)
             if (serve && level_hint(s, slot, lo) < 0xFFFFFFFFull) return shade(RT_FORM_WIDE_SERVE, lo, hi, after, true);
@@ -827,45 +827,29 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
             if (rc2 != RT_OK) return rc2;
             return shade(RT_FORM_QUAD_RESUME, lo, hi, after, true);
         };
+        auto shade_small = [&](int lo, int hi, int after) -> int { const int r = shade_small_run(lo, hi, after); ++small_runs; return r; };
         int small_lo = -1;      // first level of the run of small levels not shaded yet
-        // The tail (opt-in, option "tail_rays"): from the first level on behind which every level is expected to hold at most
-        // that many rays, closest hits, light loops and folds of all those levels are ONE launch (k_tail) on the caller's
-        // stream instead of two to three dependent launches per level. Same bytes; measured SLOWER on MI355X (bunny_1080p
-        // one frame at a time 0.71 -> 0.75 ms with levels 3..10 in the tail, batched 0.296 -> 0.337): a level costs the
-        // latency of its longest ray (12-35 us) either way, and a grid barrier across the 8 XCDs (L2 write-back, agent-
-        // scope atomic and poll, invalidate: 6-9 us, then cold caches) is no cheaper than a launch boundary (~5 us).
+        // The tail (option "tail_rays"): from the first level on that, together with everything deeper, is expected to hold
+        // at most that many rays, ONE launch traces every such ray and its whole subtree depth first, one ray per quad
+        // (k_tail), instead of one dependent closest-hit launch per level; the light loops of all those entries are part of
+        // the last run of small levels, and k_fold_tree folds the subtrees. Same bytes and ray counts.
         int lv_tail = levels + 1;
-        const uint32_t tail_wg = uint32_t(s->knobs.tail_wg);
         {
-            const uint64_t thr = uint64_t(s->knobs.tail);      // experiments and tests: rays per level, 0 = never
-            if (meshes && thr && !s->count_work && !wave_log)
-                while (lv_tail > 1 && level_hint(s, slot, lv_tail - 1) <= thr) --lv_tail;
+            const uint64_t thr = uint64_t(s->knobs.tail);      // rays; 0 = never
+            uint64_t below = 0;
+            if (meshes && thr && !wave_log)
+                for (int l = levels; l >= 1; --l) {
+                    below += level_hint(s, slot, l);
+                    if (below > thr) break;
+                    lv_tail = l;
+                }
         }
         for (int lv = 0; lv <= levels; ++lv) {
             if (lv == lv_tail) {
-                if (small_lo >= 0) {     // shade the small levels before the tail
-                    if (overlap) HIP_TRY(record(2 * lv));
-                    if ((rc = shade_small(small_lo, lv - 1, 2 * lv)) != RT_OK) return rc;
-                    small_lo = -1;
-                }
                 LevelArgs T = A;
-#ifdef RT_EXPERIMENTS
-                uint4* tail_log = nullptr;      // diagnostics (RT_TAIL_LOG): per-phase times of two E workgroups -> file
-                if (!s->knobs.tail_log_path.empty() && hipMalloc(reinterpret_cast<void**>(&tail_log), sizeof(uint4) * 128) == hipSuccess) {
-                    hipMemsetAsync(tail_log, 0, sizeof(uint4) * 128, sa);
-                    T.wave_log = tail_log;
-                }
-#endif
-                if ((rc = timed_launch(J, sa, RT_K_EXTEND_QUAD, [&] { launch_tail(s->d, T, lv_tail, levels, pc->tail_bar, tail_wg, sa); })) != RT_OK) return rc;
-#ifdef RT_EXPERIMENTS
-                if (tail_log) {
-                    uint4 h[128];
-                    hipStreamSynchronize(sa);
-                    hipMemcpy(h, tail_log, sizeof h, hipMemcpyDeviceToHost);
-                    if (FILE* f = std::fopen(s->knobs.tail_log_path.c_str(), "wb")) { std::fwrite(h, sizeof(uint4), 128, f); std::fclose(f); }
-                    hipFree(tail_log);
-                }
-#endif
+                T.level = lv; T.level_hi = lv;
+                if ((rc = timed_launch(J, sa, RT_K_EXTEND_QUAD, [&] { launch_tail(s->count_work, s->d, T, pc->tail_levels, small_grid(s, slot, lv, lv), sa); })) != RT_OK) return rc;
+                if (small_lo < 0) small_lo = lv;      // its hits are shaded with the run of small levels that ends the pass
                 break;
             }
             LevelArgs B = A;
@@ -934,7 +918,11 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
             }
         // (folding the deep levels, which hold few nodes, by ONE workgroup in one launch was measured again with the sharded
         // pool: 85 us against 9 launches x 5 us, 0.706 vs 0.686 ms/frame)
-        const int fold_hi = std::min(levels, lv_tail) - 1;      // (the tail folds its own levels)
+        const int fold_hi = std::min(levels, lv_tail) - 1;      // (the tail's levels are folded as subtrees)
+        if (lv_tail <= levels) {
+            A.level = lv_tail; A.level_hi = lv_tail;
+            launch_fold_tree(s->d, A, uint32_t(std::min<uint64_t>(1024u, level_hint(s, slot, lv_tail) / 48u + 2u * RT_SHARDS)), sa);
+        }
         // (the deep levels, a few hundred nodes each, folded by ONE 16-wave workgroup with a workgroup barrier per level:
         // measured no different, 0.685 against 0.676 ms one frame at a time - a level's fold is ~5 us of dependent loads
         // - counters, node, children - whether it is a launch of its own or not; all levels that way: 85 us against 9 x 5)
@@ -1203,7 +1191,8 @@ static int render_frame(rt_scene* s, const rt_camera* cam, uint32_t n_frames, co
             const PassCounters& pc = s->h_counters[r.slot];
             // level 0: every valid sample is one trace() call; deeper levels: appended entries
             for (int k = 0; k < RT_STAT_SHARDS; ++k) stats->shadow_rays += pc.shadow[k];
-            for (int lv = 1; lv < RT_MAX_LEVELS; ++lv) stats->level_rays[lv] += pc.appended(lv) - pc.cancel[lv];
+            // (k_tail counts every entry of its subtrees in the level behind its roots and keeps the true levels apart)
+            for (int lv = 1; lv < RT_MAX_LEVELS; ++lv) stats->level_rays[lv] += (pc.tail_levels[lv] ? pc.tail_levels[lv] : pc.appended(lv)) - pc.cancel[lv];
             for (int sh = 0; sh < RT_WORK_SHARDS; ++sh) for (int k = 0; k < RT_N_KINDS; ++k) add_work(w[k], pc.work[sh][k]);
         }
         for (int k = 0; k < RT_N_KINDS; ++k) s->last_work[k] = w[k];

@@ -1130,9 +1130,14 @@ __device__ __forceinline__ bool fetch_ray(const LevelArgs& A, uint32_t begin, ui
 // (reference src/raytracer.cpp:302-308, 347-396), the node record and the hit record for k_shade.
 // active: this lane / quad holds pool entry i; valid: the entry has a ray; writer: the lane that stores (all lanes in
 // the per-lane kernels, lane 0 of the quad in the quad kernels). Called with the whole wave converged.
+// level: the entry's recursion level (A.level in the level-synchronous kernels; per quad in k_tail). kids (or null):
+// the child rays and their pool entries, for a caller that goes on with them itself.
+struct Children { bool refl, refr; uint32_t i_refl, i_refr; Ray r_refl, r_refr; };
+#define NODE_LEVEL_SHIFT 8u      // node_b.w bits 8..11: the entry's recursion level (the `return red` exit un-counts children by level)
 __device__ __forceinline__ void extend_finish(const DScene& S, const LevelArgs& A, uint32_t i, bool active, bool valid,
                                               bool writer, const Ray& ray, const HitState& h, uint32_t next_base,
-                                              uint32_t next_end, uint32_t* next_count, uint32_t extra_flags) {
+                                              uint32_t next_end, uint32_t* next_count, uint32_t extra_flags,
+                                              int level, Children* kids = nullptr) {
     uint4 rec_b = make_uint4(RT_NO_CHILD, RT_NO_CHILD, 0, 0);
     bool want_refl = false, want_refr = false;
     Ray r_refl, r_refr;
@@ -1148,7 +1153,7 @@ __device__ __forceinline__ void extend_finish(const DScene& S, const LevelArgs& 
             const bool reflective = mp->reflective != 0, refractive = mp->refractive != 0;
             const float bias = 0.0001f;                                                  // raytracer.cpp:286
             hitPt = ray_point(ray, h.dist);
-            const int depth = A.level + 1;                                               // raytracer.cpp:347
+            const int depth = level + 1;                                                 // raytracer.cpp:347
             V3 refractNormal = h.n;
             float cosI = 0, cosT = 0, sinSqrPhit = 0, n1 = 0, n2 = 0, n = 0;
             if (refractive && depth <= A.max_depth) {                                    // raytracer.cpp:357-381
@@ -1182,6 +1187,7 @@ __device__ __forceinline__ void extend_finish(const DScene& S, const LevelArgs& 
     }
 
     // append child rays to the next level of the wave's shard: one atomic per wave
+    const bool any_refl = want_refl, any_refr = want_refr;      // (in every lane of a quad)
     want_refl = want_refl && writer;
     want_refr = want_refr && writer;
     uint32_t s1, s2;
@@ -1206,8 +1212,13 @@ __device__ __forceinline__ void extend_finish(const DScene& S, const LevelArgs& 
             *A.overflow = 1;
         }
     }
+    if (kids) {      // (a child that did not fit the pool does not exist: the pass is flagged as overflowed)
+        // (the quad kernels' writer is lane 0 of the quad: its slots go to the quad's other lanes, which hold the same rays)
+        kids->i_refl = dpp_u<QP_BCAST(0)>(rec_b.x); kids->refl = any_refl && kids->i_refl != RT_NO_CHILD; kids->r_refl = r_refl;
+        kids->i_refr = dpp_u<QP_BCAST(0)>(rec_b.y); kids->refr = any_refr && kids->i_refr != RT_NO_CHILD; kids->r_refr = r_refr;
+    }
     if (active && writer) {
-        rec_b.w |= extra_flags;
+        rec_b.w |= extra_flags | ((uint32_t)level << NODE_LEVEL_SHIFT);
         A.node_b[i] = rec_b;
         if (rec_b.w & NODE_HIT) {
             A.hit_n[i] = make_float4(h.n.x, h.n.y, h.n.z, h.tmpdist);
@@ -1366,7 +1377,7 @@ __device__ __forceinline__ void extend_wide_body(const DScene& S, const LevelArg
             A.hit_p[i] = make_float4(h.dist, __int_as_float(h.cur), __uint_as_float(h.mat), 0);
         }
         extend_finish(S, A, i, active && !parked, valid && !parked, true, ray, h, lane_read(next_base_l, shard),
-                      A.n0 + (shard + 1u) * A.sub_cap, sc->level + (A.level + 1), 0u);
+                      A.n0 + (shard + 1u) * A.sub_cap, sc->level + (A.level + 1), 0u, A.level);
     }
     if (COUNT) {
         const uint32_t steps = wave_sum(wk.wave_nodes + wk.wave_tris);
@@ -1394,8 +1405,8 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WPE
 // k_extend_quad: one ray per quad. FRESH: all rays of the level from the start (levels with few rays: no per-lane
 // kernel runs for them). !FRESH: the rays k_extend_wide queued, resumed at the mesh they stopped at.
 // The body works for "virtual" workgroup vblock of vgrid single-wave workgroups (the kernel: blockIdx.x of gridDim.x; the
-// tail kernel k_tail: one of the waves of its role) with `lds_stack` = this wave's 16-column traversal stack. `direct`:
-// group = virtual block (k_tail) instead of the CU-aware mapping of group_of.
+// caller's choice) with `lds_stack` = this wave's 16-column traversal stack. `direct`: group = virtual block instead of
+// the CU-aware mapping of group_of.
 template <int SRC, bool FRESH, bool COUNT>
 __device__ __forceinline__ void extend_quad_body(const DScene& S, const LevelArgs& A, uint32_t* lds_stack, uint32_t vblock, uint32_t vgrid, bool direct) {
     const uint32_t quad = (threadIdx.x & 63u) >> 2, j = threadIdx.x & 3u;
@@ -1462,7 +1473,7 @@ __device__ __forceinline__ void extend_quad_body(const DScene& S, const LevelArg
         if (!(RT_DBG(A.debug) & 2u)) closest_loop<true, COUNT>(S, ray, valid, k0, h, qs, wk);
         if (COUNT) wk.trav_ticks += wall_clock64() - c0;
         extend_finish(S, A, i, active, valid, j == 0, ray, h, lane_read(next_base_l, shard), A.n0 + (shard + 1u) * A.sub_cap,
-                      A.sc[shard].level + (A.level + 1), FRESH ? 0u : NODE_PARKED);
+                      A.sc[shard].level + (A.level + 1), FRESH ? 0u : NODE_PARKED, A.level);
         }
     }
     if (COUNT) flush_work(A.work, 2, wk);
@@ -1525,12 +1536,7 @@ __device__ __forceinline__ void shade_ray(const DScene& S, const LevelArgs& A_, 
         A.node_a[i] = make_float4(1, 0, 0, 0);
         if (b.w & NODE_FOLD) {      // children were appended speculatively: ignore them, and un-count them
             A.node_b[i].w = b.w & ~NODE_FOLD;      // (the marks the level-0 quad kernels select by stay as they are)
-            int lv = 0;         // the level of entry i: walk its sub-pool
-            if (i >= A.n0) {
-                const uint32_t sh = (i - A.n0) / A.sub_cap, off = (i - A.n0) - sh * A.sub_cap;
-                uint64_t e = 0;
-                for (lv = 1; lv < RT_MAX_LEVELS; ++lv) { e += A.sc[sh].level[lv]; if (off < e) break; }
-            }
+            const int lv = (int)((b.w >> NODE_LEVEL_SHIFT) & 15u);      // the level of entry i
             atomicAdd(A.cancelled + lv + 1, (b.x != RT_NO_CHILD ? 1u : 0u) + (b.y != RT_NO_CHILD ? 1u : 0u));
         }
     } else if (b.w & NODE_FOLD) {
@@ -1759,103 +1765,108 @@ __global__ __launch_bounds__(256) void k_fold(DScene S, LevelArgs A) {
     fold_body(S, A, blockIdx.x * 4u + (threadIdx.x >> 6), gridDim.x * 4u);
 }
 
-// ---- the tail of the recursion in ONE launch --------------------------------------------------------------------
+// ---- the tail of the recursion in ONE launch, NOT level-synchronous --------------------------------------------------
 // The deep levels of a frame hold a few thousand rays, then a few dozen (bunny_1080p: 4753, 3327, 636, 174, 40, 20, 17,
-// 8 at levels 3..10). One launch per level for the closest hits, a share of two shade launches and a fold launch each
-// make a chain of ~25 dependent launches that lasts as long as the rest of the frame (one frame at a time: levels 3..10
-// 217 us, the last light loops 60 us, the folds 90 us of 0.75 ms) while the chip is idle. k_tail runs levels
-// lv_first..lv_last in one launch of a few hundred small workgroups that are all resident at once:
-//   * the first half of the workgroups ("E") finds the closest hits level by level (one ray per quad, the body of
-//     k_extend_quad<1, true>), with a grid barrier among themselves where a launch boundary was: an arrival counter in
-//     device memory (one per pass, cleared with the pass counters), phase p is over when it reaches p x n_e;
-//   * the other half ("S") runs the light loops (the body of k_shade_quad<0>) of every level the counter says is complete,
-//     next to the E workgroups' deeper levels - nothing but the fold waits for them - and then arrives at a second counter;
-//   * the E workgroups wait for that one and fold the levels deepest first (k_fold's body), a barrier per level.
-// Visibility: every wave's stores are complete (workgroup-scope release: they are in the XCD's L2) before its
-// workgroup's barrier; thread 0 then releases at agent scope (L2 write-back: the workgroups sit on different XCDs) and
-// bumps the counter; a waiting workgroup's thread 0 polls it with agent-scope loads, and after the workgroup barrier
-// every wave acquires at agent scope (L1 / non-local L2 lines dropped). The level counters are atomics (L2).
-// Exit condition every wave reaches: the grid is far smaller than what the chip holds (256 workgroups of 4 waves, 16 KB
-// LDS), so every workgroup becomes resident as soon as other launches' waves retire; a poll that still sees no
-// progress after RT_TAIL_SPIN_LIMIT rounds (~1 s) raises `abort`, which every poll loop reads, flags the pass as
-// overflowed (the frame is reported as failed / re-run by the host, never silently wrong) and all workgroups return.
-#define RT_TAIL_WG_WAVES 4u
-#define RT_TAIL_SPIN_LIMIT (1u << 20)
-__device__ __forceinline__ bool tail_poll(uint32_t* ctr, uint32_t target, uint32_t* abort_flag, uint32_t* overflow) {      // one thread
-    for (uint32_t spins = 0;; ++spins) {
-        if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
-        if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
-        if (spins > RT_TAIL_SPIN_LIMIT) {
-            __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(overflow, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return false;
+// 8 at levels 3..10). One closest-hit launch per level makes a chain of dependent launches, each as long as the LONGEST
+// ray of its level (12-35 us) plus a launch boundary, while the chip is idle: 217 us of a 0.63 ms frame, and 9 fold
+// launches behind them. (Round 2 put these levels into one launch WITH a grid barrier per level - same critical path,
+// the barrier no cheaper than a launch boundary: measured slower, removed.) Here each quad takes one ray of level
+// A.level (the tail's root level) and follows that ray's OWN subtree depth first: closest hit, Fresnel and children
+// exactly as k_extend_quad (closest_loop + extend_finish), then it goes on with the reflection child and keeps the
+// refraction child (a node has at most these two) on a per-quad stack in LDS - at most one entry per level. No barrier,
+// no wave ever waits for another: a wave lasts as long as the longest TREE among its quads, not the sum of the longest
+// ray of every level. Every entry of the subtrees is appended to the shard's region behind the root level and counted
+// in the counter of level A.level + 1, whatever its own level (the level-synchronous layout - level k + 1 behind level k
+// - cannot be kept without a barrier); its true level goes into node_b.w (NODE_LEVEL_SHIFT) and into tail_levels[] for
+// the ray statistics. The light loops of all these entries are one k_shade_quad launch over "levels" A.level ..
+// A.level + 1; k_fold_tree then folds each root's subtree.
+#define RT_TAIL_STACK 16      // pending refraction children per quad: one per level at most
+template <bool COUNT>
+__global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void k_tail(DScene S, LevelArgs A, uint32_t* tail_levels) {
+    __shared__ uint32_t lds_stack[RT_QSTACK * 16];
+    __shared__ float pend[RT_TAIL_STACK][8][16];      // [depth][entry, level, o.xyz, d.xyz][quad]
+    const uint32_t quad = (threadIdx.x & 63u) >> 2, j = threadIdx.x & 3u;
+    uint32_t* qs = lds_stack + quad;
+    const ShardView v = shard_view(A, A.level, A.level);
+    const uint32_t next_base_l = v.start + v.cnt;
+    const Groups G = make_groups<true>(v.start, v.cnt);
+    Work wk = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (COUNT) { wk.t_start = wall_clock64(); wk.c_start = clock64(); }
+    for (uint32_t grp = blockIdx.x; grp < G.total; grp += gridDim.x) {
+        uint32_t shard, pos, lim;
+        locate(G, grp, shard, pos, lim);
+        const uint32_t next_base = lane_read(next_base_l, shard), next_end = A.n0 + (shard + 1u) * A.sub_cap;
+        uint32_t* next_count = A.sc[shard].level + (A.level + 1);
+        bool have = quad < G.R && pos + quad < lim;
+        uint32_t i = pos + quad;
+        int level = A.level;
+        int sp = 0;
+        Ray ray;
+        ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 0);
+        if (have) fetch_ray<1>(A, 0, i, ray);
+        while (__any(have)) {                                                                // wave-uniform
+            HitState h = fresh_hit();
+            closest_loop<true, COUNT>(S, ray, have, 0, h, qs, wk);
+            Children kids;
+            extend_finish(S, A, i, have, have, j == 0, ray, h, next_base, next_end, next_count, 0u, level, &kids);
+            if (have) {
+                const uint32_t n_kids = (kids.refl ? 1u : 0u) + (kids.refr ? 1u : 0u);
+                if (j == 0 && n_kids) atomicAdd(tail_levels + level + 1, n_kids);
+                if (kids.refl && kids.refr && sp < RT_TAIL_STACK) {      // (sp < RT_TAIL_STACK always: one pending child per level)
+                    if (j == 0) {
+                        pend[sp][0][quad] = __uint_as_float(kids.i_refr); pend[sp][1][quad] = __int_as_float(level + 1);
+                        pend[sp][2][quad] = kids.r_refr.o.x; pend[sp][3][quad] = kids.r_refr.o.y; pend[sp][4][quad] = kids.r_refr.o.z;
+                        pend[sp][5][quad] = kids.r_refr.d.x; pend[sp][6][quad] = kids.r_refr.d.y; pend[sp][7][quad] = kids.r_refr.d.z;
+                    }
+                    ++sp;
+                }
+                if (kids.refl) { i = kids.i_refl; ray = kids.r_refl; ++level; }
+                else if (kids.refr) { i = kids.i_refr; ray = kids.r_refr; ++level; }
+                else if (sp > 0) {      // (LDS operations of one wave complete in order: the quad's own words are there)
+                    --sp;
+                    i = __float_as_uint(pend[sp][0][quad]); level = __float_as_int(pend[sp][1][quad]);
+                    ray.o = mk(pend[sp][2][quad], pend[sp][3][quad], pend[sp][4][quad]);
+                    ray.d = mk(pend[sp][5][quad], pend[sp][6][quad], pend[sp][7][quad]);
+                } else have = false;
+            }
         }
-        __builtin_amdgcn_s_sleep(4);
     }
+    if (COUNT) flush_work(A.work, 2, wk);
 }
-// All threads of the workgroup. `arrive` (or null): counter to bump once this workgroup's stores are visible; `wait`
-// (or null): counter to poll until it reaches `target`. Returns false when the launch was aborted.
-__device__ __forceinline__ bool tail_sync(uint32_t* arrive, uint32_t* wait, uint32_t target, uint32_t* abort_flag, uint32_t* overflow,
-                                          uint32_t* lds_ok) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        if (arrive) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+// Folds the subtree under every entry of level A.level (the tail's roots): one thread per root walks its tree depth
+// first with an explicit stack (entries + which child is next) and applies node_color - the reference's expression
+// (raytracer.cpp:399-406) - to a node once its children are final. The trees of a tail are chains with an occasional
+// fork, a dozen nodes: one launch of a few dependent loads per node instead of a launch per level.
+__global__ __launch_bounds__(64) void k_fold_tree(DScene S, LevelArgs A) {
+    __shared__ uint32_t st_i[RT_MAX_LEVELS + 1][64];
+    __shared__ uint32_t st_k[RT_MAX_LEVELS + 1][64];
+    const ShardView v = shard_view(A, A.level, A.level);
+    const Groups G = make_groups<false>(v.start, v.cnt);
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t grp = blockIdx.x; grp < G.total; grp += gridDim.x) {
+        uint32_t shard, pos, lim;
+        locate(G, grp, shard, pos, lim);
+        if (pos + lane >= lim) continue;
+        int sp = 0;
+        st_i[0][lane] = pos + lane; st_k[0][lane] = 0;
+        while (sp >= 0) {
+            const uint32_t i = st_i[sp][lane], k = st_k[sp][lane];
+            const uint4 b = A.node_b[i];
+            if (!(b.w & NODE_FOLD)) { --sp; continue; }                       // final already (or no children)
+            const uint32_t child = k == 0 ? b.x : b.y;
+            if (k < 2) {
+                st_k[sp][lane] = k + 1;
+                if (child != RT_NO_CHILD && sp < RT_MAX_LEVELS && (A.node_b[child].w & NODE_FOLD)) { ++sp; st_i[sp][lane] = child; st_k[sp][lane] = 0; }
+                continue;
+            }
+            const V3 c = node_color(S, A.node_a, A.node_b, i);
+            float4 a = A.node_a[i];
+            a.x = c.x; a.y = c.y; a.z = c.z;
+            A.node_a[i] = a;
+            A.node_b[i].w = b.w & ~NODE_FOLD;
+            --sp;
         }
-        *lds_ok = (!wait || tail_poll(wait, target, abort_flag, overflow)) ? 1u : 0u;
-    }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    return *lds_ok != 0u;
-}
-template <bool GPOW>
-__global__ __launch_bounds__(64 * RT_TAIL_WG_WAVES) __attribute__((amdgpu_waves_per_eu(4))) void k_tail(DScene S, LevelArgs A, int lv_first, int lv_last, uint32_t* bar) {
-    __shared__ uint32_t lds_stacks[RT_TAIL_WG_WAVES][RT_QSTACK * 16];
-    __shared__ uint32_t lds_ok;
-    const uint32_t wave = threadIdx.x >> 6;
-    uint32_t* lds = lds_stacks[wave];
-    const uint32_t n_e = gridDim.x >> 1, n_s = gridDim.x - n_e;      // workgroups per role
-    uint32_t* arrive_e = bar, * done_s = bar + 1, * abort_flag = bar + 2;
-    if (blockIdx.x < n_e) {
-        const uint32_t vb = blockIdx.x * RT_TAIL_WG_WAVES + wave, vg = n_e * RT_TAIL_WG_WAVES;
-        uint32_t phase = 0;
-        // diagnostics (RT_TAIL_LOG): workgroup 0 and the last E workgroup log {phase start, work done, barrier passed} in 10-ns ticks
-        uint4* log = (RT_LOG_PTR(A.wave_log) && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == n_e - 1)) ? A.wave_log + (blockIdx.x ? 64 : 0) : nullptr;
-        for (int lv = lv_first; lv <= lv_last; ++lv) {
-            const unsigned long long t0 = log ? wall_clock64() : 0ull;
-            A.level = lv; A.level_hi = lv;
-            extend_quad_body<1, true, false>(S, A, lds, vb, vg, true);
-            const unsigned long long t1 = log ? wall_clock64() : 0ull;
-            ++phase;
-            if (!tail_sync(arrive_e, arrive_e, phase * n_e, abort_flag, A.overflow, &lds_ok)) return;
-            if (log) log[phase] = make_uint4((uint32_t)t0, (uint32_t)t1, (uint32_t)wall_clock64(), (uint32_t)lv);
-        }
-        {
-            const unsigned long long t0 = log ? wall_clock64() : 0ull;
-            if (!tail_sync(nullptr, done_s, n_s, abort_flag, A.overflow, &lds_ok)) return;
-            if (log) log[32] = make_uint4((uint32_t)t0, (uint32_t)t0, (uint32_t)wall_clock64(), 99u);
-        }
-        for (int lv = lv_last - 1; lv >= lv_first; --lv) {
-            const unsigned long long t0 = log ? wall_clock64() : 0ull;
-            A.level = lv; A.level_hi = lv;
-            fold_body(S, A, vb, vg);
-            const unsigned long long t1 = log ? wall_clock64() : 0ull;
-            ++phase;
-            if (lv > lv_first && !tail_sync(arrive_e, arrive_e, phase * n_e, abort_flag, A.overflow, &lds_ok)) return;
-            if (log) log[phase] = make_uint4((uint32_t)t0, (uint32_t)t1, (uint32_t)wall_clock64(), (uint32_t)(100 + lv));
-        }
-    } else {
-        const uint32_t vb = (blockIdx.x - n_e) * RT_TAIL_WG_WAVES + wave, vg = n_s * RT_TAIL_WG_WAVES;
-        // (level by level: every S wave must cut the same range into the same groups, so the range cannot depend on how far
-        // each of them sees the E workgroups have come)
-        for (int lv = lv_first; lv <= lv_last; ++lv) {
-            if (!tail_sync(nullptr, arrive_e, (uint32_t)(lv - lv_first + 1) * n_e, abort_flag, A.overflow, &lds_ok)) return;
-            A.level = lv; A.level_hi = lv;
-            shade_quad_body<0, false, GPOW>(S, A, lds, vb, vg, true);
-        }
-        tail_sync(done_s, nullptr, 0u, abort_flag, A.overflow, &lds_ok);
     }
 }
 
@@ -2210,9 +2221,12 @@ void launch_set_aa(const float* aa_xy, uint32_t n_points, float* dst, hipStream_
     std::memcpy(p.xy, aa_xy, sizeof(float) * 2 * std::min<uint32_t>(n_points, RT_MAX_AA_POINTS));
     hipLaunchKernelGGL(k_set_aa, dim3(1), dim3(256), 0, st, p, 2u * std::min<uint32_t>(n_points, RT_MAX_AA_POINTS), dst);
 }
-void launch_tail(const DScene& S, const LevelArgs& A, int lv_first, int lv_last, uint32_t* bar, uint32_t workgroups, hipStream_t st) {
-    if (S.generic_pow) hipLaunchKernelGGL((k_tail<true>), dim3(workgroups), dim3(64 * RT_TAIL_WG_WAVES), 0, st, S, A, lv_first, lv_last, bar);
-    else hipLaunchKernelGGL((k_tail<false>), dim3(workgroups), dim3(64 * RT_TAIL_WG_WAVES), 0, st, S, A, lv_first, lv_last, bar);
+void launch_tail(bool count, const DScene& S, const LevelArgs& A, uint32_t* tail_levels, uint32_t grid, hipStream_t st) {
+    if (count) hipLaunchKernelGGL((k_tail<true>), dim3(grid), dim3(RT_BLOCK), 0, st, S, A, tail_levels);
+    else hipLaunchKernelGGL((k_tail<false>), dim3(grid), dim3(RT_BLOCK), 0, st, S, A, tail_levels);
+}
+void launch_fold_tree(const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st) {
+    hipLaunchKernelGGL(k_fold_tree, dim3(grid), dim3(64), 0, st, S, A);
 }
 void launch_fold(const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st) {
     hipLaunchKernelGGL(k_fold, dim3(grid), dim3(256), 0, st, S, A);

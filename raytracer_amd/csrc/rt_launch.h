@@ -161,10 +161,11 @@ void launch_shade(int form, bool count, const DScene& S, const LevelArgs& A, uin
 void launch_set_frame_params(const FrameParamsBatch& p, uint32_t n_frames, FrameParams* dst, void* clear, size_t clear_bytes, hipStream_t st);   // clear: 16-byte multiple
 void launch_set_aa(const float* aa_xy, uint32_t n_points, float* dst, hipStream_t st);      // host pattern -> device, as kernel arguments
 void launch_fold(const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st);
-// levels lv_first..lv_last (>= 1) in one launch of `workgroups` (even, at most RT_TAIL_MAX_WG: all resident at once)
-// small workgroups: closest hits, light loops, folds (k_tail). bar: 3 words, zero at the start of the launch
-#define RT_TAIL_MAX_WG 256u
-void launch_tail(const DScene& S, const LevelArgs& A, int lv_first, int lv_last, uint32_t* bar, uint32_t workgroups, hipStream_t st);
+// A.level = the tail's root level (>= 1): every ray of that level and its whole subtree in one launch, one ray per quad,
+// depth first (k_tail); tail_levels: [RT_MAX_LEVELS + 4] per-level entry counts, zero at the start of the pass
+void launch_tail(bool count, const DScene& S, const LevelArgs& A, uint32_t* tail_levels, uint32_t grid, hipStream_t st);
+// folds the subtrees under the entries of level A.level (the tail's roots), one thread per root
+void launch_fold_tree(const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st);
 void launch_resolve(const DScene& S, const LevelArgs& A, uint8_t* out, hipStream_t st);
 void launch_resolve_rgb(const DScene& S, const LevelArgs& A, float* rgb, hipStream_t st);
 void launch_untile(const UntileArgs& U, const uint8_t* tiles, uint8_t* out, hipStream_t st);
