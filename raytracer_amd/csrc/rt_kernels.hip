@@ -67,12 +67,41 @@ __device__ __forceinline__ float min_std(float a, float b) { return (b < a) ? b 
 __device__ __forceinline__ V3 ld3(const float* p) { return mk(p[0], p[1], p[2]); }
 __device__ __forceinline__ V3 f4xyz(float4 v) { return mk(v.x, v.y, v.z); }
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 struct Ray { V3 o, d; };
+
+// The per-frame pool (child rays, node and hit records) is written once and read once or twice, gigabytes of it per
+// frame at 4K / 8K; the BVH's nodes and leaf blocks are what every ray comes back to. Pool accesses therefore carry
+// the non-temporal hint (`nt`: the line is a streaming one for the L2's replacement), so that they do not push the
+// tree out of the 4-MB L2s.
+#ifndef RT_STREAM_POOL
+#define RT_STREAM_POOL 1      // (0: A/B builds)
+#endif
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 pool_ld(const float4* p) {
+    if (!RT_STREAM_POOL) return *p;
+    const f32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint4 pool_ld(const uint4* p) {
+    if (!RT_STREAM_POOL) return *p;
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void pool_st(float4* p, float4 v) {
+    if (!RT_STREAM_POOL) { *p = v; return; }
+    f32x4_t w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+    __builtin_nontemporal_store(w, reinterpret_cast<f32x4_t*>(p));
+}
+__device__ __forceinline__ void pool_st(uint4* p, uint4 v) {
+    if (!RT_STREAM_POOL) { *p = v; return; }
+    u32x4 w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+    __builtin_nontemporal_store(w, reinterpret_cast<u32x4*>(p));
+}
 
 // Wave-uniform, read-only scene tables (object table, models, lights) are read through the constant address space:
 // the compiler may then use scalar loads (s_load_dwordx4/x8 into SGPRs) although the kernel also stores to global
 // memory; through a plain pointer it falls back to per-lane vector loads whose latency sits in every object test.
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define RT_CONSTANT __attribute__((address_space(4)))
 // First statement of a block guarded by a wave-uniform test: keeps that test a scalar branch of its own (s_cmp +
 // s_cbranch). Without it the compiler folds it into the per-lane condition inside the block - compare, select, and
@@ -1117,7 +1146,7 @@ __device__ __forceinline__ bool fetch_ray(const LevelArgs& A, uint32_t begin, ui
         }
         ray = cast_ray(cam, A.aa, x, y, k);
     } else if (SRC == 1) {
-        const float4 o = A.rays[2 * (size_t)(i - A.n0)], d = A.rays[2 * (size_t)(i - A.n0) + 1];
+        const float4 o = pool_ld(A.rays + 2 * (size_t)(i - A.n0)), d = pool_ld(A.rays + 2 * (size_t)(i - A.n0) + 1);
         ray.o = f4xyz(o); ray.d = f4xyz(d);
     } else {
         const float* p = A.user_rays + 6 * (size_t)i;
@@ -1195,8 +1224,8 @@ __device__ __forceinline__ void extend_finish(const DScene& S, const LevelArgs& 
     if (want_refl) {
         const uint64_t slot = (uint64_t)next_base + s1;
         if (slot < next_end) {
-            A.rays[2 * (size_t)(slot - A.n0)] = make_float4(r_refl.o.x, r_refl.o.y, r_refl.o.z, 0);
-            A.rays[2 * (size_t)(slot - A.n0) + 1] = make_float4(r_refl.d.x, r_refl.d.y, r_refl.d.z, 0);
+            pool_st(A.rays + 2 * (size_t)(slot - A.n0), make_float4(r_refl.o.x, r_refl.o.y, r_refl.o.z, 0));
+            pool_st(A.rays + 2 * (size_t)(slot - A.n0) + 1, make_float4(r_refl.d.x, r_refl.d.y, r_refl.d.z, 0));
             rec_b.x = (uint32_t)slot;
         } else {
             *A.overflow = 1;
@@ -1205,8 +1234,8 @@ __device__ __forceinline__ void extend_finish(const DScene& S, const LevelArgs& 
     if (want_refr) {
         const uint64_t slot = (uint64_t)next_base + s2;
         if (slot < next_end) {
-            A.rays[2 * (size_t)(slot - A.n0)] = make_float4(r_refr.o.x, r_refr.o.y, r_refr.o.z, 0);
-            A.rays[2 * (size_t)(slot - A.n0) + 1] = make_float4(r_refr.d.x, r_refr.d.y, r_refr.d.z, 0);
+            pool_st(A.rays + 2 * (size_t)(slot - A.n0), make_float4(r_refr.o.x, r_refr.o.y, r_refr.o.z, 0));
+            pool_st(A.rays + 2 * (size_t)(slot - A.n0) + 1, make_float4(r_refr.d.x, r_refr.d.y, r_refr.d.z, 0));
             rec_b.y = (uint32_t)slot;
         } else {
             *A.overflow = 1;
@@ -1219,13 +1248,13 @@ __device__ __forceinline__ void extend_finish(const DScene& S, const LevelArgs& 
     }
     if (active && writer) {
         rec_b.w |= extra_flags | ((uint32_t)level << NODE_LEVEL_SHIFT);
-        A.node_b[i] = rec_b;
+        pool_st(A.node_b + i, rec_b);
         if (rec_b.w & NODE_HIT) {
-            A.hit_n[i] = make_float4(h.n.x, h.n.y, h.n.z, h.tmpdist);
-            A.hit_p[i] = make_float4(hitPt.x, hitPt.y, hitPt.z, rCoef);
+            pool_st(A.hit_n + i, make_float4(h.n.x, h.n.y, h.n.z, h.tmpdist));
+            pool_st(A.hit_p + i, make_float4(hitPt.x, hitPt.y, hitPt.z, rCoef));
         } else if (rec_b.w & NODE_VALID) {
             const u32x4 bg = ldc4(A.fp->background, 0);
-            A.node_a[i] = make_float4(__uint_as_float(bg.x), __uint_as_float(bg.y), __uint_as_float(bg.z), 0);   // raytracer.cpp:302-304
+            pool_st(A.node_a + i, make_float4(__uint_as_float(bg.x), __uint_as_float(bg.y), __uint_as_float(bg.z), 0));   // raytracer.cpp:302-304
         } else {
             A.node_a[i] = make_float4(0, 0, 0, 0);
         }
@@ -1540,11 +1569,11 @@ __device__ __forceinline__ void shade_ray(const DScene& S, const LevelArgs& A_, 
             atomicAdd(A.cancelled + lv + 1, (b.x != RT_NO_CHILD ? 1u : 0u) + (b.y != RT_NO_CHILD ? 1u : 0u));
         }
     } else if (b.w & NODE_FOLD) {
-        A.node_a[i] = make_float4(color.x, color.y, color.z, rCoef);
+        pool_st(A.node_a + i, make_float4(color.x, color.y, color.z, rCoef));
     } else {
         const rt_material m = *mp;
         const V3 c = finish_color(color, m, rCoef, mk(0, 0, 0), mk(0, 0, 0));
-        A.node_a[i] = make_float4(c.x, c.y, c.z, rCoef);
+        pool_st(A.node_a + i, make_float4(c.x, c.y, c.z, rCoef));
     }
 }
 
@@ -1576,10 +1605,10 @@ __device__ __forceinline__ void shade_wide_body(const DScene& S, const LevelArgs
         bool hit;
         {
             const LevelArgs Af = (RT_RELOAD_FOR(PACKET)) ? reload_level_args() : A_;
-            if (i < lim) b = Af.node_b[i];
+            if (i < lim) b = pool_ld(Af.node_b + i);
             hit = (b.w & (NODE_HIT | NODE_PARKED)) == NODE_HIT;
             if (!__any(hit)) continue;                                                       // wave-uniform
-            if (hit) { hn = Af.hit_n[i]; hp = Af.hit_p[i]; }
+            if (hit) { hn = pool_ld(Af.hit_n + i); hp = pool_ld(Af.hit_p + i); }
         }
         int parked;
         shade_ray<false, COUNT, GPOW, PACKET>(S, A, i, b, hit, true, f4xyz(hn), f4xyz(hp), hp.w, hn.w, 0, 0, false, mk(0, 0, 0), lds, wk,
@@ -1673,14 +1702,14 @@ __device__ __forceinline__ void shade_quad_body(const DScene& S, const LevelArgs
             i = A.queue_e[pos + quad].x;
         }
         uint4 b = make_uint4(0, 0, 0, 0);
-        if (active) b = A.node_b[i];
+        if (active) b = pool_ld(A.node_b + i);
         const bool hit = (b.w & NODE_HIT) != 0;
         if (!__any(hit)) continue;                                                           // wave-uniform
         float4 hn = make_float4(0, 0, 0, 0), hp = make_float4(0, 0, 0, 0);
         V3 color = mk(0, 0, 0);
         float tmpdist = 0;
         if (hit) {
-            hn = A.hit_n[i]; hp = A.hit_p[i];
+            hn = pool_ld(A.hit_n + i); hp = pool_ld(A.hit_p + i);
             tmpdist = hn.w;
             if (!FRESH) {
                 const float4 c = A.node_a[i];
@@ -1706,8 +1735,8 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WPE
 // Colour of pool node i once its children (one level deeper) are final.
 __device__ __forceinline__ V3 node_color(const DScene& S, const float4* __restrict__ node_a, const uint4* __restrict__ node_b,
                                          uint32_t i) {
-    const float4 a = node_a[i];
-    const uint4 b = node_b[i];
+    const float4 a = pool_ld(node_a + i);
+    const uint4 b = pool_ld(node_b + i);
     if (!(b.w & NODE_FOLD)) return mk(a.x, a.y, a.z);
     const rt_material m = S.materials[b.z];
     V3 refl = mk(0, 0, 0), refr = mk(0, 0, 0);
