@@ -504,9 +504,37 @@ __device__ __forceinline__ uint32_t s_is_valid(uint32_t key) {
     asm("s_not_b32 %0, %1\n\ts_min_u32 %0, %0, 1" : "=s"(r) : "s"(key) : "scc");
     return r;
 }
+// Leaves worked off ACROSS the lanes (shadow packets). A packet reaches a leaf when any of its rays hits the leaf's box,
+// but on average only a quarter of its rays do, and in the flat form every lane tests all (up to) four triangles:
+// 3.6 x ~50 vector instructions per leaf step, three quarters of the lanes for nothing. The node step knows which
+// lanes hit each child (the ballots it branches on), so those masks travel with the stack entries (two more lane
+// stacks). A leaf reached by <= 16 live rays is then tested in ONE go: the reaching lanes put their rays into LDS by
+// rank, quad q reads ray q, lane j of the quad fetches triangle j of the block itself (three 16-B vector loads, as the
+// quad kernels do) and tests it, and a reaching lane whose quad reports a hit leaves the packet. A leaf that no live
+// ray reaches any more (they were occluded on the way) is skipped. Same answer: every (reaching ray, triangle) pair is
+// tested with the same arithmetic; a ray that did not hit the box cannot hit a triangle inside it.
+// MEASURED AND NOT USED (default 0; A/B builds). The test itself gets cheaper - level-0 shade launch of bunny_1080p 60.5 M
+// -> 56.4 M vector instructions, 0.152 -> 0.140 ms; 10 M-triangle field at 1080p 1.54 -> 1.20 ms - but the path needs ~25
+// more VGPRs (the quad's ray and triangle next to the lane's own state): at the kernel's 7 waves per SIMD they spill
+// (8K field 402 -> 416 ms, 4K glass scene 27.4 -> 29.1, c3 0.133 -> 0.149), and at 6 waves the batched frames, which live
+// on occupancy, lose more than the leaves win (bunny_1080p 0.2105 -> 0.219 ms per frame; the same kernel WITHOUT
+// compaction at 6 waves: 0.219). Only the field at 1080p 4 spp gained end to end (3.93 -> 3.76 ms).
+#ifndef RT_LEAF_COMPACT
+#define RT_LEAF_COMPACT 0
+#endif
+#ifndef RT_LEAF_COMPACT_TRI
+#define RT_LEAF_COMPACT_TRI 0     // the compacted leaf's triangles: 0 three vector loads per lane, 1 scalar loads + per-lane selects
+#endif
+#ifndef RT_LEAF_COMPACT_MAX
+#define RT_LEAF_COMPACT_MAX 16u   // (A/B builds: a leaf reached by more live rays is tested in the flat form)
+#endif
+#define RT_PK_LDS_WORDS 128      // per wave: 16 rays x (origin, tmax, direction, pad)
 template <bool ANY, bool COUNT>
 __device__ __forceinline__ void packet_traverse(const DScene& S, uint32_t root, bool have, const Ray& ray, float tmax,
-                                                QuadHit& out, Work& wk) {
+                                                QuadHit& out, Work& wk, uint32_t* pk_lds = nullptr) {
+    const bool compact = ANY && RT_LEAF_COMPACT && RT_TRI_MASKS_ANY && RT_ANY_UNORDERED && pk_lds != nullptr;      // (compile time but for the pointer)
+    int mlo = 0, mhi = 0;                   // lane k = the lanes that hit the box of stack entry k (compact)
+    unsigned long long cur_m = ~0ull;       // ... of the node or leaf being visited
     const V3 inv = mk(safe_rcp(ray.d.x), safe_rcp(ray.d.y), safe_rcp(ray.d.z));
     const V3 ood = mk(ray.o.x * inv.x, ray.o.y * inv.y, ray.o.z * inv.z);
     float best = ANY ? tmax : FLT_MAX, bu = 0, bv = 0;
@@ -523,6 +551,7 @@ __device__ __forceinline__ void packet_traverse(const DScene& S, uint32_t root, 
             if (COUNT) { wk.nodes += __builtin_amdgcn_inverse_ballot_w64(live_m); wk.wave_nodes += wave_once(); }
             const float cull = ANY ? best : best * 1.000001f;
             uint32_t key[4], ref[4];
+            unsigned long long cm[4] = {0, 0, 0, 0};      // (compact) the live lanes that hit each child
             // the whole node is requested at once (scalar loads return in any order, so the only wait there is is for
             // all of them: four requests one after the other would be four latencies), and nothing below branches
             u32x4 nd[8];
@@ -547,6 +576,7 @@ __device__ __forceinline__ void packet_traverse(const DScene& S, uint32_t root, 
                 if ((ANY && RT_ANY_UNORDERED) || RT_CLOSEST_ORDER == 2) {       // 1 = hit by some ray
                     asm("s_cmp_lg_u32 %4, -1\n\ts_cselect_b64 %0, %3, 0\n\ts_and_b64 %0, %2, %0\n\ts_cselect_b32 %1, 1, 0"
                         : "=&s"(m), "=s"(key[c]) : "s"(hm), "s"(live_m), "s"(ref[c]) : "scc");
+                    cm[c] = m;
                     continue;
                 }
                 // distance of the first ray that hits the child (tn >= 0: its bits order like its value); none: last
@@ -558,6 +588,21 @@ __device__ __forceinline__ void packet_traverse(const DScene& S, uint32_t root, 
             if ((ANY && RT_ANY_UNORDERED) || RT_CLOSEST_ORDER == 2) {
                 // shadow rays: any occluder will do, so the children are visited in the order they lie in the node - no
                 // v_readlane of the distances, no sort (same answer: occluded or not does not depend on the order)
+                if (compact) {
+#pragma unroll
+                    for (int c = 3; c >= 1; --c) {
+                        stack = write_lane(stack, ref[c], sp);
+                        mlo = write_lane(mlo, (uint32_t)cm[c], sp); mhi = write_lane(mhi, (uint32_t)(cm[c] >> 32), sp);
+                        sp += key[c];
+                    }
+                    if (key[0]) { cur = ref[0]; cur_m = cm[0]; }
+                    else if (sp) {
+                        --sp; cur = (uint32_t)__builtin_amdgcn_readlane(stack, (int)sp);
+                        cur_m = (uint32_t)__builtin_amdgcn_readlane(mlo, (int)sp) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(mhi, (int)sp) << 32);
+                    }
+                    else cur = RT_DONE;
+                    continue;
+                }
                 stack = write_lane(stack, ref[3], sp); sp += key[3];
                 stack = write_lane(stack, ref[2], sp); sp += key[2];
                 stack = write_lane(stack, ref[1], sp); sp += key[1];
@@ -602,6 +647,49 @@ __device__ __forceinline__ void packet_traverse(const DScene& S, uint32_t root, 
             const uint32_t cnt = ((cur >> 27) & 15u) + 1u;
             const RT_CONSTANT u32x4* lp = (const RT_CONSTANT u32x4*)(const void*)(S.leaves) + 12u * (size_t)(cur & RT_LEAF_START_MASK);
             if (COUNT) { wk.tris += __builtin_amdgcn_inverse_ballot_w64(live_m) ? cnt : 0u; wk.wave_tris += wave_once(); }
+            const unsigned long long reach = cur_m & live_m;
+            const uint32_t n_reach = compact ? (uint32_t)__popcll(reach) : 64u;
+            if (compact && n_reach <= RT_LEAF_COMPACT_MAX) {
+                if (n_reach) {
+                    const uint32_t lane = lane_id(), q = lane >> 2, j = lane & 3u;
+#if RT_LEAF_COMPACT_TRI == 0
+                    const float4* tp = reinterpret_cast<const float4*>(S.leaves + (cur & RT_LEAF_START_MASK)) + j;
+                    const float4 q0 = tp[0], q1 = tp[4], q2 = tp[8];            // triangle j of the block (requested first: the longest wait)
+#else
+                    // the block by scalar loads (as the flat form), triangle j picked per lane: 27 selects, no vector memory
+                    float4 q0, q1, q2;
+                    {
+                        u32x4 lf[12];
+#pragma unroll
+                        for (int c = 0; c < 12; ++c) lf[c] = lp[c];
+                        const bool j1 = (j & 1u) != 0, j2 = (j & 2u) != 0;
+#define RT_PICK(c, k) __uint_as_float(j2 ? (j1 ? lf[c + 3].k : lf[c + 2].k) : (j1 ? lf[c + 1].k : lf[c].k))
+                        q0 = make_float4(RT_PICK(0, x), RT_PICK(0, y), RT_PICK(0, z), 0);
+                        q1 = make_float4(RT_PICK(4, x), RT_PICK(4, y), RT_PICK(4, z), 0);
+                        q2 = make_float4(RT_PICK(8, x), RT_PICK(8, y), RT_PICK(8, z), 0);
+#undef RT_PICK
+                    }
+#endif
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(reach >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)reach, 0u));
+                    const bool mine = __builtin_amdgcn_inverse_ballot_w64(reach);
+                    float4* slot = reinterpret_cast<float4*>(pk_lds);
+                    if (mine) {
+                        slot[2u * rank] = make_float4(ray.o.x, ray.o.y, ray.o.z, tmax);
+                        slot[2u * rank + 1u] = make_float4(ray.d.x, ray.d.y, ray.d.z, 0.0f);
+                    }
+                    const float4 ro = slot[2u * q], rd = slot[2u * q + 1u];      // (LDS operations of one wave complete in order)
+                    Ray qr;
+                    qr.o = f4xyz(ro); qr.d = f4xyz(rd);
+                    unsigned long long m = __builtin_amdgcn_ballot_w64(q < n_reach) & __builtin_amdgcn_ballot_w64(j < cnt);
+                    float tt = 0, u = 0, v = 0;
+                    tri_isect_packet<0>(f4xyz(q0), f4xyz(q1), f4xyz(q2), qr, m, tt, u, v);
+                    m &= __builtin_amdgcn_ballot_w64(tt < ro.w);
+                    if (m) {                                                                             // wave-uniform
+                        const bool occ = mine && ((uint32_t)(m >> (4u * rank)) & 15u) != 0u;      // my quad reports a hit
+                        live_m &= ~__builtin_amdgcn_ballot_w64(occ);
+                    }
+                }
+            } else {
             // two triangles per request (6 x 16 B, one wait): four requests one after the other are four latencies, the whole
             // block at once (48 SGPRs) makes the kernel spill scalars around the loop - and every spilled SGPR is a VALU
             // instruction (v_writelane / v_readlane), which is what this path is short of
@@ -645,9 +733,13 @@ __device__ __forceinline__ void packet_traverse(const DScene& S, uint32_t root, 
                     }
                 }
             }
+            }
             if (ANY && !RT_TRI_MASKS_ANY) live_m = __builtin_amdgcn_ballot_w64(live);
             if (ANY && live_m == 0) cur = RT_DONE;
-            else if (sp) { --sp; cur = (uint32_t)__builtin_amdgcn_readlane(stack, (int)sp); }
+            else if (sp) {
+                --sp; cur = (uint32_t)__builtin_amdgcn_readlane(stack, (int)sp);
+                if (compact) cur_m = (uint32_t)__builtin_amdgcn_readlane(mlo, (int)sp) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane(mhi, (int)sp) << 32);
+            }
             else cur = RT_DONE;
         }
     }
@@ -872,7 +964,7 @@ __device__ __forceinline__ bool occluded_loop(const DScene& S, const Ray& ray, b
                 if (PACKET == 2) {
                     serve_traverse<true, COUNT>(S, m.root, need, ray, ldist, q, qs, wk);
                 } else if (PACKET) {
-                    if (__ballot(need)) packet_traverse<true, COUNT>(S, m.root, need, ray, ldist, q, wk);
+                    if (__ballot(need)) packet_traverse<true, COUNT>(S, m.root, need, ray, ldist, q, wk, qs);
                 } else if (need) {
                     quad_traverse<true, COUNT>(S, m.root, true, ray, ldist, q, qs, wk);
                 }
@@ -1037,6 +1129,9 @@ __device__ __forceinline__ bool map_pixel(const PixelMap& pm, uint64_t q, uint32
 #endif
 #ifndef RT_WPE_PK
 #define RT_WPE_PK 7      // the per-lane kernels when they carry the packet traversal (5/6: bunny_1080p 0.292 ms, 7: 0.281, 8: 0.301; 4K glass scene 43.8 / 42.4 / 43.5)
+#endif
+#ifndef RT_WPE_PKS
+#define RT_WPE_PKS RT_WPE_PK      // ... the light-loop kernel of the two
 #endif
 #define RT_RUN_LOG2 3u    // see group_of: runs of 8 groups (measured: 1, 2, 4 and 16 within 3 %; 64+ and one strip per CU 5-20 % slower). Experiments: RT_DEBUG_SKIP = run_log2 << 8
 #define NODE_HIT 4u      // has a hit record: k_shade computes its colour
@@ -1634,8 +1729,9 @@ __device__ __forceinline__ void shade_wide_body(const DScene& S, const LevelArgs
     }
 }
 template <bool COUNT, bool GPOW, bool PACKET>
-__global__ __launch_bounds__(RT_WIDE_BLOCK_MAX) __attribute__((amdgpu_waves_per_eu(PACKET ? RT_WPE_PK : RT_WPE_SW))) void k_shade_wide(DScene S, LevelArgs A) {
-    shade_wide_body<COUNT, GPOW, PACKET ? 1 : 0>(S, A, nullptr);
+__global__ __launch_bounds__(RT_WIDE_BLOCK_MAX) __attribute__((amdgpu_waves_per_eu(PACKET ? RT_WPE_PKS : RT_WPE_SW))) void k_shade_wide(DScene S, LevelArgs A) {
+    extern __shared__ uint32_t pk_lds[];      // packet_traverse: the rays of a compacted leaf, RT_PK_LDS_WORDS per wave (dynamic: sized for the launch's waves)
+    shade_wide_body<COUNT, GPOW, PACKET ? 1 : 0>(S, A, PACKET ? pk_lds + (threadIdx.x >> 6) * RT_PK_LDS_WORDS : nullptr);
 }
 // the hits of levels >= 1, one per lane, shadow rays through meshes by quad service
 template <bool COUNT, bool GPOW>
@@ -2220,7 +2316,7 @@ static void launch_shade_t(int form, const DScene& S, const LevelArgs& A, dim3 g
         b = dim3(64u * wide_waves());
         g = dim3((g.x + wide_waves() - 1u) / wide_waves());
         // the hits of primary rays: their shadow rays are coherent too (rt_trace's caller-supplied rays need not be)
-        if (S.packet && (A.level == 0 || S.packet >= 2) && (!A.user_rays || S.user_packet)) hipLaunchKernelGGL((k_shade_wide<COUNT, GPOW, true>), g, b, 0, st, S, A);
+        if (S.packet && (A.level == 0 || S.packet >= 2) && (!A.user_rays || S.user_packet)) hipLaunchKernelGGL((k_shade_wide<COUNT, GPOW, true>), g, b, RT_LEAF_COMPACT ? wide_waves() * RT_PK_LDS_WORDS * 4u : 0u, st, S, A);
         else hipLaunchKernelGGL((k_shade_wide<COUNT, GPOW, false>), g, b, 0, st, S, A);
     }
     else if (form == RT_FORM_WIDE_SERVE) hipLaunchKernelGGL((k_shade_serve<COUNT, GPOW>), g, b, 0, st, S, A);

@@ -20,5 +20,5 @@ for w in ${WORKLOADS:-bunny_1080p}; do for rep in 1 2; do for l in $LIBS; do
   case $w in c5_field_10m_8k_64spp) st=2; wu=2;; c4_bunny_glass_4k_16spp) st=16; wu=4;; esac
   lib=$PWD/tools/bin/librt_amd_$l.so; [ "$l" = tree ] && lib=$PWD/raytracer_amd/csrc/librt_amd.so
   RT_AMD_LIB=$lib timeout -k 10 300 python bench.py --no-cpu-baseline --workload $w --steps $st --warmup $wu 2>/dev/null | python3 -c "
-import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$w $l', 'batched', round(d['ms_per_step'],4), 'latency', round(d.get('ms_per_frame_latency',0),4), 'level0', {k.split('<')[0]: round(v,4) for k,v in d['roofline']['level0_launch_ms'].items()}, d['frame_identical_to_1gpu'], flush=True)" || exit 1
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$w $l', 'batched', round(d['ms_per_step'],4), 'latency', round(d.get('ms_per_frame_latency',0),4), 'level0', {k.split('<')[0]: round(v,4) for k,v in d['roofline']['level0_launch_ms'].items()}, 'batch', round(d['roofline'].get('batched_launch',{}).get('ms_per_frame',0),4), {k.split('<')[0]: round(v,4) for k,v in d['roofline'].get('batched_call_serial',{}).get('ms_per_frame_by_kernel',{}).items()}, d['frame_identical_to_1gpu'], flush=True)" || exit 1
 done; done; done
