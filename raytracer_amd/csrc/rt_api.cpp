@@ -171,6 +171,9 @@ struct rt_scene {
     bool graph_ok = true;
     ShardCounters* h_hint = nullptr;     // pinned: level sizes of the most recent pass (async copy, read without a sync:
                                          // only a scheduling hint, results never depend on it)
+    int hint_depth = RT_MAX_LEVELS;      // recursion depth of the frame the hints were taken from
+    uint32_t* h_tail_hint = nullptr;     // pinned, [pass][RT_MAX_LEVELS + 4]: k_tail's entries per TRUE level (it counts them all
+                                         // in the level behind its roots; without these the next frame would take the deeper levels for empty)
     PassCounters* d_counters = nullptr;
     PassCounters* h_counters = nullptr;   // pinned
     float* d_aa = nullptr;
@@ -211,6 +214,7 @@ static int free_scene(rt_scene* s) {
     if (s->copy_stream) hipStreamDestroy(s->copy_stream);
     if (s->h_counters) hipHostFree(s->h_counters);
     if (s->h_hint) hipHostFree(s->h_hint);
+    if (s->h_tail_hint) hipHostFree(s->h_tail_hint);
     if (s->h_overflow) hipHostFree(s->h_overflow);
     for (auto& g : s->graphs) hipGraphExecDestroy(g.exec);
     hipFree(s->d_fp);
@@ -386,6 +390,7 @@ extern "C" int rt_scene_create_ex(const rt_flat_scene* sc, int device, uint32_t 
         hipHostMalloc(reinterpret_cast<void**>(&s->h_counters), sizeof(PassCounters) * RT_MAX_PASSES) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&s->h_hint), sizeof(ShardCounters) * RT_SHARDS * RT_MAX_PASSES) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&s->h_overflow), 64) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&s->h_tail_hint), sizeof(uint32_t) * (RT_MAX_LEVELS + 4) * RT_MAX_PASSES) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&s->d_fp), sizeof(FrameParams) * RT_MAX_BATCH) != hipSuccess ||
         hipMalloc(reinterpret_cast<void**>(&s->d_aa), sizeof(float) * 2 * (RT_MAX_AA_POINTS + 1)) != hipSuccess ||
         hipEventCreate(&s->ev_begin) != hipSuccess || hipEventCreate(&s->ev_end) != hipSuccess) {
@@ -394,6 +399,7 @@ extern "C" int rt_scene_create_ex(const rt_flat_scene* sc, int device, uint32_t 
         return RT_ERR_DEVICE;
     }
     std::memset(s->h_hint, 0, sizeof(ShardCounters) * RT_SHARDS * RT_MAX_PASSES);
+    std::memset(s->h_tail_hint, 0, sizeof(uint32_t) * (RT_MAX_LEVELS + 4) * RT_MAX_PASSES);
     *s->h_overflow = 0;
     for (int p = 0; p < RT_MAX_PASSES; ++p)
         for (int i = 0; i < RT_MAX_LEVELS + 4; ++i) s->h_hint[size_t(p) * RT_SHARDS].level[i] = 0xFFFFFFFFu;   // unknown: assume large levels
@@ -633,6 +639,8 @@ static int timed_launch(FrameJob& J, hipStream_t st, uint8_t kind, F&& launch) {
 // picture bounces nothing, the glass in the middle a lot - but pass k of the next frame looks like pass k of this
 // one); unknown = large.
 static uint64_t level_hint(const rt_scene* s, uint32_t pass, int l) {
+    if (l > s->hint_depth) return 0xFFFFFFFFull;      // the frame the hints come from did not go that deep: unknown, not empty
+    if (const uint32_t t = s->h_tail_hint[size_t(pass) * (RT_MAX_LEVELS + 4) + l]) return t;      // the level was part of a tail
     uint64_t n = 0;
     const ShardCounters* h = s->h_hint + size_t(pass) * RT_SHARDS;
     for (uint32_t k = 0; k < RT_SHARDS; ++k) n += h[k].level[l];
@@ -935,6 +943,7 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
         HIP_TRY(hipGetLastError());
         // level sizes of this pass -> scheduling hint of the next one (no sync; see h_hint)
         HIP_TRY(hipMemcpyAsync(s->h_hint + size_t(slot) * RT_SHARDS, pc->sc, sizeof(ShardCounters) * RT_SHARDS, hipMemcpyDeviceToHost, sa));
+        HIP_TRY(hipMemcpyAsync(s->h_tail_hint + size_t(slot) * (RT_MAX_LEVELS + 4), pc->tail_levels, sizeof(uint32_t) * (RT_MAX_LEVELS + 4), hipMemcpyDeviceToHost, sa));
         if (recs) recs->push_back({px0 + done, cnt, slot});
         if (J.progress && recs) {       // event number = index of the pass in recs
             while (s->ev_pass.size() < recs->size()) {
@@ -1005,6 +1014,9 @@ static int render_frame(rt_scene* s, const rt_camera* cam, uint32_t n_frames, co
     // pixels, i.e. at 16+ samples per pixel: measured 1426 -> 844 ms (level 0) -> 791 ms (all levels) per frame on the 10 M-
     // triangle scene at 64 spp and 78 -> 69 -> 55..67 ms on the 4K 16 spp glass scene, but 6.3 -> 10.9 ms at 4 spp.
     if (s->packet_auto && s->n_models) s->d.packet = spp >= 16 ? 2u : 1u;
+    // (the hints this frame schedules by were left by the previous frame, whose depth is s->hint_depth; the frames after
+    // this one read this frame's: the new depth takes effect when this call returns)
+    struct DepthGuard { rt_scene* s; int d; ~DepthGuard() { s->hint_depth = d; } } depth_guard{s, s->has_bounce ? prm->max_depth : 0};
     FrameJob J{};
     J.s = s; J.st = st; J.d_out = d_out; J.timed = stats != nullptr;
     J.progress = sync ? progress : nullptr; J.progress_user = progress_user;

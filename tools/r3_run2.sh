@@ -2,7 +2,7 @@
 # counters of the current kernels, then the bench that reads them
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p profiles/r3 gpurun_out
-timeout -k 10 300 python -u -m pytest tests/test_tiles_gloo.py -m gpu -x -q --timeout 280 --timeout-method thread 2>&1 | tail -5
+true
 for w in ${WORKLOADS:-bunny_1080p}; do
   bash tools/collect_counters.sh $w ${LIM:-240} > gpurun_out/counters_table_$w.txt 2>&1 || { tail -5 gpurun_out/counters_table_$w.txt; exit 1; }
   cp gpurun_out/counters_$w.json profiles/r3/
