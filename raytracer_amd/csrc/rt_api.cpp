@@ -78,6 +78,7 @@ static uint32_t default_pass_samples(int env_log2) {
     return 1u << k;
 }
 
+#define RT_LEVEL_GRID 8192u           // workgroups of a level >= 1 launch (grid-stride over the device-side count)
 // What a caller (a test, an experiment) may fix about the schedule instead of leaving it to the scene and the level
 // sizes: rt_scene_set_option. The same names in upper case with an RT_ prefix in the environment are read ONCE, when a
 // scene is created (tools/exp_*.sh); no call that renders reads the environment.
@@ -92,6 +93,13 @@ struct Knobs {
     int index64 = 0;              // RT_NO_FAST32: sample index arithmetic by 64-bit division even where 32 bits would do
     int chunk_log2 = RT_SHARD_CHUNK_LOG2;   // RT_CHUNK_LOG2
     int use_graph = 0;            // RT_USE_GRAPH: replay asynchronous frames as a hipGraph (measured slower)
+    // RT_WIDE_GRID: most workgroups of a per-lane launch over levels >= 1 (its waves stride over the groups). 7168 = the wave
+    // slots of the chip at the 7 waves per SIMD these kernels run at: one round, nothing waits for a slot. Measured (batched
+    // bunny_1080p / 4K glass scene / field at 1080p, ms per frame): 2048: 0.254 / 31.0 / 4.32; 5120: 0.214 / 25.5 / 3.90;
+    // 7168: 0.211 / 26.4 / 3.93; 8192: 0.214 / 26.6 / 3.93; 28672: 0.218 / 37.2 / 3.95; 262144 (a wave per group): 0.234 /
+    // 56.0 / 4.14 - more workgroups than slots only adds the per-workgroup set-up (shard views, group scan) and takes the
+    // rays out of pool order.
+    int wide_grid = 7168;
     int grid0 = 0;                // RT_GRID0: cap of the level-0 per-lane grids (0: none)
     int pass_log2 = -1;           // RT_PASS_LOG2
     int shade_streams = 3;        // RT_SHADE_STREAMS
@@ -116,6 +124,7 @@ static Knobs knobs_from_env() {
     k.chunk_log2 = int(std::min<long long>(RT_SHARD_CHUNK_LOG2_MAX, std::max(0ll, env_ll("RT_CHUNK_LOG2", k.chunk_log2))));
     k.use_graph = std::getenv("RT_USE_GRAPH") ? 1 : 0;
     k.grid0 = int(std::max(0ll, env_ll("RT_GRID0", 0)));
+    k.wide_grid = int(std::max(64ll, std::min(1ll << 22, env_ll("RT_WIDE_GRID", k.wide_grid))));
     k.pass_log2 = int(env_ll("RT_PASS_LOG2", -1));
     k.shade_streams = int(std::max(1ll, std::min(3ll, env_ll("RT_SHADE_STREAMS", 3))));
 #ifdef RT_EXPERIMENTS
@@ -132,7 +141,6 @@ static Knobs knobs_from_env() {
 #define RT_MAX_TIMED 2048
 #define RT_MAX_GRAPHS 8
 enum { RT_K_EXTEND_WIDE = 0, RT_K_SHADE_WIDE = 1, RT_K_EXTEND_QUAD = 2, RT_K_SHADE_QUAD = 3, RT_K_SHADE_PARKED = 4 };
-#define RT_LEVEL_GRID 8192u           // workgroups of a level >= 1 launch (grid-stride over the device-side count)
 
 struct rt_scene {
     int device = 0;
@@ -697,7 +705,7 @@ static uint32_t resume_grid(const rt_scene* s, uint32_t pass, int lv) {
 static uint32_t wide_grid_for(const rt_scene* s, uint32_t pass, int lo, int hi) {
     uint64_t n = 0;
     for (int l = lo; l <= hi; ++l) n += level_hint(s, pass, l);
-    return uint32_t(std::min<uint64_t>(RT_LEVEL_GRID, (n + n / 4u) / 64u + 2u * RT_SHARDS));
+    return uint32_t(std::min<uint64_t>(uint64_t(s->knobs.wide_grid), (n + n / 4u) / 64u + 2u * RT_SHARDS));
 }
 
 // Enqueue the passes covering pixels [px0, px0+npx) of the frame's pixel order, pass_px pixels at a time.
@@ -797,7 +805,7 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
                 B.level_hi = part == 0 ? 0 : hi;
                 B.wave_log = (log_shade && B.level == log_level) ? wave_log : nullptr;
                 const bool wide = form == RT_FORM_WIDE || form == RT_FORM_WIDE_SERVE;
-                const uint32_t wide_grid = (small_run && wide) ? wide_grid_for(s, slot, B.level, B.level_hi) : RT_LEVEL_GRID;
+                const uint32_t wide_grid = wide ? wide_grid_for(s, slot, B.level, B.level_hi) : RT_LEVEL_GRID;
                 const uint32_t g = wide ? (B.level_hi == 0 ? grid0 : wide_grid)
                                    : (B.level_hi == 0 ? grid0q : (form == RT_FORM_QUAD_FRESH ? small_grid(s, slot, B.level, B.level_hi)
                                                                   : small_run ? resume_grid(s, slot, B.level) : 4u * RT_LEVEL_GRID));
@@ -871,7 +879,7 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
                     if ((rc = shade_small(small_lo, lv - 1, 2 * lv)) != RT_OK) return rc;
                     small_lo = -1;
                 }
-                if ((rc = timed_launch(J, sa, RT_K_EXTEND_WIDE, [&] { launch_extend(src, RT_FORM_WIDE, s->count_work, s->d, B, lv == 0 ? grid0 : RT_LEVEL_GRID, sa); })) != RT_OK) return rc;
+                if ((rc = timed_launch(J, sa, RT_K_EXTEND_WIDE, [&] { launch_extend(src, RT_FORM_WIDE, s->count_work, s->d, B, lv == 0 ? grid0 : wide_grid_for(s, slot, lv, lv), sa); })) != RT_OK) return rc;
                 if (overlap) HIP_TRY(record(2 * lv));
                 // level 0 of a packet scene: the per-lane kernels traverse the meshes themselves, nothing is suspended
                 const bool quads = meshes && !((lv == 0 && s->d.packet) || s->d.packet >= 2);
