@@ -167,7 +167,12 @@ FULL_SIZE = {
     "c2_analytic_1080p_4spp": ("frame",),
     "c3_bunny_1080p_shadows": ("rects", [(692, 0, 16, 1080)]),
     "c4_bunny_glass_4k_16spp": ("rects", [(1088, 272, 48, 32), (1580, 1390, 32, 32)]),     # in the glass2 sphere; on the mesh
-    "c5_field_10m_8k_64spp": ("pixels", [(3840, 2721), (2560, 3456), (5000, 3000), (3000, 2400), (4400, 3900), (1200, 2900), (3846, 2727), (2553, 3449)]),  # on the blobs of the field
+    # 8 pixels on the blobs of the field, then 24 SILHOUETTE pixels: the corner rays of pixel x and x + 1 of that row hit
+    # different things (blob / floor; found with the oracle at depth 0), so the 64 samples of pixel x straddle the edge
+    "c5_field_10m_8k_64spp": ("pixels", [(3840, 2721), (2560, 3456), (5000, 3000), (3000, 2400), (4400, 3900), (1200, 2900), (3846, 2727), (2553, 3449),
+                                         (2813, 2400), (2888, 2400), (2975, 2400), (3054, 2400), (3094, 2400), (3152, 2400), (3251, 2400), (3325, 2400),
+                                         (3368, 2400), (3475, 2721), (3543, 2721), (3640, 2721), (3705, 2721), (3801, 2721), (3849, 2721), (3954, 2721),
+                                         (2361, 3456), (2462, 3456), (2557, 3456), (2653, 3456), (2768, 3456), (2869, 3456), (4428, 3900), (4488, 3900)]),
 }
 
 
