@@ -66,6 +66,8 @@ def parse_args():
                          "that many frames' rays (1..32; 1 = one call per frame)")
     ap.add_argument("--batch-samples", type=int, default=64 << 20,
                     help="a batch holds at most this many level-0 samples (frames x pixels x samples per pixel, per rank)")
+    ap.add_argument("--batch-plan", default="",
+                    help="experiments: frames per call of the timed region, one entry per call (e.g. 14,6); overrides --frames-per-batch")
     ap.add_argument("--same-camera", action="store_true", help="experiments: every frame of a batch from the reference camera")
     ap.add_argument("--bvh", default="host", choices=("host", "device"),
                     help="BVH builder: the host's SAH tree (default) or the GPU's linear BVH (RT_SCENE_BVH_DEVICE)")
@@ -248,7 +250,13 @@ def main():
     in_flight = args.frames_in_flight or (1 if (W * H * params.spp) // world >= 2 * (8 << 20) else 2)
     # ... and at least one call per slot inside the timed region, so that the calls in flight overlap (and, with several
     # ranks, the exchange of one call - gather, untile - the rendering of the other) whatever --steps is
-    B = max(1, min(32, args.frames_per_batch, args.batch_samples // max(1, (W * H * params.spp) // world), args.steps // in_flight))
+    # (one GPU: the fewest calls of at most 32 frames, evenly sized - a short run is better off as ONE large call than as
+    # one small call per slot: --steps 20 as 2 x 10 0.240-0.244 ms per frame, as 1 x 20 0.235, tools/exp_steps20b.sh)
+    per_call = args.steps // in_flight if multi else -(-args.steps // -(-args.steps // 32))
+    B = max(1, min(32, args.frames_per_batch, args.batch_samples // max(1, (W * H * params.spp) // world), per_call))
+    plan = [int(x) for x in args.batch_plan.split(",") if x]
+    if plan:
+        B = max(plan)
     # the frames of a batch are DIFFERENT pictures: camera k on a small circle through the reference camera (camera 0)
     cams = [cam] * B if args.same_camera else wl.orbit_cameras(W, H, B)
     frame_bytes = H * W * 3
@@ -332,11 +340,11 @@ def main():
                 mark()
                 mark()
 
-    def run_steps(n):
+    def run_steps(n, plan=()):
         """n frames as ceil(n / B) calls; returns the rays of those frames (rank 0 knows them)."""
         done, call, rays = 0, 0, 0
         while done < n:
-            b = min(B, n - done)
+            b = min(plan[call % len(plan)] if plan else B, n - done)
             step(call, b)
             rays += sum(cam_rays[:b]) if cam_rays else 0
             done += b
@@ -372,7 +380,7 @@ def main():
             break
     sync()
     t = time.perf_counter()
-    timed_rays = run_steps(args.steps)
+    timed_rays = run_steps(args.steps, plan)
     sync()
     elapsed = time.perf_counter() - t
     if overflowed():

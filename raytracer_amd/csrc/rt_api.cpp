@@ -87,6 +87,7 @@ struct Knobs {
     long long large_thr = -1;     // RT_LARGE_THR: rays from which a bounce level runs as per-lane kernel (+ queue); -1: expect_large's table
     int large_maxlv = -1;         // RT_LARGE_MAXLV: deepest level that may be "large"; -1 default
     int serve = -1;               // RT_SERVE: bounce levels by quad service: 0 never, 1 always, -1 by pass size
+    int shade_serve_lv = 0;       // RT_SHADE_SERVE_LV: with packets below level 0, the light loops of large levels >= this one by quad service (0: packets)
     int split_small = 1;          // RT_SPLIT_SMALL: runs of small levels shaded per lane + resuming quads (1) / one quad launch (0)
     int tiny_run = 1024;          // RT_TINY_RUN: a run of at most this many hits is one quad launch
     long long tail = 8192;        // RT_TAIL: the levels that, with everything deeper, hold at most this many rays go to k_tail (0: never)
@@ -118,6 +119,7 @@ static Knobs knobs_from_env() {
     k.large_maxlv = int(env_ll("RT_LARGE_MAXLV", k.large_maxlv));
     k.serve = int(env_ll("RT_SERVE", k.serve));
     k.split_small = int(env_ll("RT_SPLIT_SMALL", k.split_small));
+    k.shade_serve_lv = int(env_ll("RT_SHADE_SERVE_LV", k.shade_serve_lv));
     k.tiny_run = int(std::max(0ll, env_ll("RT_TINY_RUN", k.tiny_run)));
     k.tail = std::max(0ll, env_ll("RT_TAIL", k.tail));
     k.index64 = std::getenv("RT_NO_FAST32") ? 1 : 0;
@@ -477,6 +479,7 @@ extern "C" int rt_scene_set_option(rt_scene* s, const char* name, int64_t value)
     else if (n == "large_max_level") k.large_maxlv = value < 0 ? -1 : int(std::min<int64_t>(value, RT_MAX_LEVELS));
     else if (n == "serve") k.serve = value < 0 ? -1 : (value ? 1 : 0);
     else if (n == "split_small") k.split_small = value ? 1 : 0;
+    else if (n == "shade_serve_level") k.shade_serve_lv = int(value);
     else if (n == "tiny_run") k.tiny_run = int(std::max<int64_t>(0, std::min<int64_t>(value, 1 << 30)));
     else if (n == "tail_rays") k.tail = std::max<int64_t>(0, value);
     else if (n == "index64") k.index64 = value ? 1 : 0;
@@ -891,7 +894,8 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
                 // them behind the extend launch of level 1 / 2 / 3 instead, so that the chain's first large levels have the
                 // chip to themselves, was measured slower: one frame at a time 0.686 -> 0.706 / 0.72 / 0.745 ms.)
                 const int ev_w = 2 * lv;
-                if ((rc = shade(RT_FORM_WIDE, lv, lv, ev_w)) != RT_OK) return rc;
+                const bool shade_by_service = !quads && lv >= 1 && s->knobs.shade_serve_lv > 0 && lv >= s->knobs.shade_serve_lv;
+                if ((rc = shade(shade_by_service ? RT_FORM_WIDE_SERVE : RT_FORM_WIDE, lv, lv, ev_w)) != RT_OK) return rc;
                 if (quads) {
                     if ((rc = shade(RT_FORM_QUAD_RESUME, lv, lv, ev_w)) != RT_OK) return rc;
                     if ((rc = shade(RT_FORM_QUAD_PARKED, lv, lv, 2 * lv + 1)) != RT_OK) return rc;

@@ -818,6 +818,125 @@ __device__ __forceinline__ void serve_traverse(const DScene& S, uint32_t root, b
     }
 }
 
+// ---- lane traversal: one ray per LANE, every lane walks the tree by itself --------------------------------------
+// Quad service keeps 16 rays of a wave on their way at a time, and a ray's traversal is a chain of dependent fetches:
+// where the tree does not fit the L2 (the 10 M-triangle field: 700 MB) or shares it with the pool streaming through
+// (the 4K glass scene), the bounce-level kernels wait for memory two thirds of their time at a fraction of the HBM
+// bandwidth - they are bound by how many fetch chains the chip holds, not by instructions. Here each lane fetches and
+// slab-tests the four children of ITS node (eight 16-B loads), descends into the nearest hit child and pushes the others
+// onto its own stack (LDS, [entry][lane]: conflict-free), then tests the up to four triangles of its leaf one after the
+// other: 64 chains per wave instead of 16, for about the same instructions per ray while the lanes keep busy (a wave's
+// node loop runs until every lane has reached a leaf, its leaf step until every lane is through).
+// Same results as quad_traverse on each ray: every triangle a ray hits is found (boxes only cull, with the same
+// conservative slab test), the closest hit is the lexicographic minimum of (t, original face index), ANY stops at the
+// first triangle with EPS < t < tmax.
+// The stack holds RT_LANE_STACK entries per lane (the wave's quad-service block of LDS, used as [20][64]); a node step
+// writes its four children above the top and keeps those that were hit, so a lane that arrives at a node with more
+// than RT_LANE_STACK_LIMIT entries gives up (returns false) and its ray is traversed again by quad service, whose
+// stack the builders bound: the result never depends on the short stack.
+// MEASURED AND NOT USED (default 0; A/B builds, tools/r3_run8.sh: same bytes in every parity test, also with a stack
+// limit of 1, where every ray takes the fallback). Slower wherever quad service runs today: bunny_1080p in batches 0.212
+// -> 0.233 ms per frame (k_extend_serve 0.062 -> 0.084 ms, k_shade_serve 0.045 -> 0.059), 10 M-triangle field at 1080p 3.93
+// -> 4.34 ms, 4K glass scene 27.4 -> 34.2 ms. A lane's eight 16-B loads lie in ONE cache line and the lines of the 64 lanes
+// are all different: a node step is 8 vector-memory instructions of 64 line look-ups each where a quad step is 2
+// instructions of 16 (each quad's four lanes read 64 contiguous bytes) - four times the work for the L1's address and tag
+// pipeline per ray, the unit these latency-bound kernels queue at - and the leaf step tests a lane's four triangles one
+// after the other at the pace of the slowest lane. More fetch chains per wave do not pay for that.
+#ifndef RT_LANE_TRAVERSE
+#define RT_LANE_TRAVERSE 0      // (1: A/B builds)
+#endif
+#define RT_LANE_STACK (RT_SERVE_LDS / 64)
+#ifndef RT_LANE_STACK_LIMIT
+#define RT_LANE_STACK_LIMIT (RT_LANE_STACK - 4)      // (test builds: 1, so that the fallback runs)
+#endif
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ bool lane_traverse(const DScene& S, uint32_t root, bool need, const Ray& ray, float tmax,
+                                              QuadHit& out, uint32_t* lds, Work& wk) {
+    uint32_t* st = lds + lane_id();
+    const V3 inv = mk(safe_rcp(ray.d.x), safe_rcp(ray.d.y), safe_rcp(ray.d.z));
+    const V3 ood = mk(ray.o.x * inv.x, ray.o.y * inv.y, ray.o.z * inv.z);
+    float best = ANY ? tmax : FLT_MAX, bu = 0, bv = 0;
+    uint32_t face = 0xFFFFFFFFu;
+    uint32_t cur = need ? root : RT_DONE;      // RT_NO_CHILD == RT_DONE for an empty model
+    uint32_t sp = 0;
+    bool ok = true;
+    while (__builtin_amdgcn_ballot_w64(cur != RT_DONE)) {
+        while (!(cur & RT_LEAF_BIT)) {      // (per lane; RT_DONE has the leaf bit)
+            if (sp > RT_LANE_STACK_LIMIT) { ok = false; cur = RT_DONE; break; }
+            const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
+            const float4 a0 = np[0], a1 = np[1], a2 = np[2], a3 = np[3], b0 = np[4], b1 = np[5], b2 = np[6], b3 = np[7];
+            if (COUNT) wk.nodes += 1;
+            const float cull = ANY ? best : best * 1.000001f;
+            const uint32_t r0 = __float_as_uint(a0.w), r1 = __float_as_uint(a1.w), r2 = __float_as_uint(a2.w), r3 = __float_as_uint(a3.w);
+            bool h0, h1, h2, h3;
+            const float t0 = slab(a0.x, a0.y, a0.z, b0.x, b0.y, b0.z, inv, ood, cull, h0);
+            const float t1 = slab(a1.x, a1.y, a1.z, b1.x, b1.y, b1.z, inv, ood, cull, h1);
+            const float t2 = slab(a2.x, a2.y, a2.z, b2.x, b2.y, b2.z, inv, ood, cull, h2);
+            const float t3 = slab(a3.x, a3.y, a3.z, b3.x, b3.y, b3.z, inv, ood, cull, h3);
+            h0 = h0 && r0 != RT_NO_CHILD; h1 = h1 && r1 != RT_NO_CHILD; h2 = h2 && r2 != RT_NO_CHILD; h3 = h3 && r3 != RT_NO_CHILD;
+            // entry distance >= 0: its bits order like its value; the slot in the two lowest bits makes the keys distinct
+            const uint32_t k0 = h0 ? ((__float_as_uint(t0) & ~3u) | 0u) : 0xFFFFFFFFu;
+            const uint32_t k1 = h1 ? ((__float_as_uint(t1) & ~3u) | 1u) : 0xFFFFFFFFu;
+            const uint32_t k2 = h2 ? ((__float_as_uint(t2) & ~3u) | 2u) : 0xFFFFFFFFu;
+            const uint32_t k3 = h3 ? ((__float_as_uint(t3) & ~3u) | 3u) : 0xFFFFFFFFu;
+            const uint32_t kmin = min(min(k0, k1), min(k2, k3));
+            // the nearest is visited next; the other hit children are pushed as they lie in the node (every child is written
+            // above the top, the top moves past those that stay)
+            st[sp * 64u] = r0; sp += (h0 && k0 != kmin) ? 1u : 0u;
+            st[sp * 64u] = r1; sp += (h1 && k1 != kmin) ? 1u : 0u;
+            st[sp * 64u] = r2; sp += (h2 && k2 != kmin) ? 1u : 0u;
+            st[sp * 64u] = r3; sp += (h3 && k3 != kmin) ? 1u : 0u;
+            if (kmin == 0xFFFFFFFFu) {
+                if (sp) { --sp; cur = st[sp * 64u]; } else cur = RT_DONE;
+            } else {
+                cur = k0 == kmin ? r0 : k1 == kmin ? r1 : k2 == kmin ? r2 : r3;
+            }
+        }
+        if (cur != RT_DONE) {
+            const uint32_t cnt = ((cur >> 27) & 15u) + 1u;
+            const float4* tp = reinterpret_cast<const float4*>(S.leaves + (cur & RT_LEAF_START_MASK));
+            if (COUNT) wk.tris += cnt;
+            bool got = false;
+#pragma unroll
+            for (uint32_t t = 0; t < RT_MAX_LEAF_TRIS; ++t) {
+                if (t < cnt) {
+                    const float4 q0 = tp[t], q1 = tp[4 + t], q2 = tp[8 + t];
+                    float tt, u, v;
+                    if (tri_isect(f4xyz(q0), f4xyz(q1), f4xyz(q2), ray, tt, u, v)) {
+                        const uint32_t f = __float_as_uint(q0.w);
+                        if (ANY) {
+                            got = got || tt < tmax;
+                        } else if (tt < best || (tt == best && f < face)) {
+                            best = tt; bu = u; bv = v; face = f;
+                        }
+                    }
+                }
+            }
+            if (ANY && got) { face = 0; cur = RT_DONE; }
+            else if (sp) { --sp; cur = st[sp * 64u]; }
+            else cur = RT_DONE;
+        }
+    }
+    out.t = best; out.u = bu; out.v = bv; out.face = face;
+    return ok;
+}
+// The mesh traversal of the per-lane kernels that suspend nothing (PACKET == 2): every needing lane by itself, and the
+// few whose short stack did not do by quad service. Called with all 64 lanes active.
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ void mesh_serve(const DScene& S, uint32_t root, bool need, const Ray& ray, float tmax,
+                                           QuadHit& out, uint32_t* lds, Work& wk) {
+    if (!RT_LANE_TRAVERSE) { serve_traverse<ANY, COUNT>(S, root, need, ray, tmax, out, lds, wk); return; }
+    out.face = 0xFFFFFFFFu; out.t = 0; out.u = 0; out.v = 0;
+    if (__builtin_amdgcn_ballot_w64(need) == 0) return;                                // wave-uniform
+    const bool ok = lane_traverse<ANY, COUNT>(S, root, need, ray, tmax, out, lds, wk);
+    const bool redo = need && !ok;
+    if (__builtin_amdgcn_ballot_w64(redo)) {                                           // wave-uniform, rare
+        QuadHit q;
+        serve_traverse<ANY, COUNT>(S, root, redo, ray, tmax, q, lds, wk);
+        if (redo) out = q;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // The two object loops of trace(), each in two forms:
 //   QUAD = false  one ray per lane (64 per wave). Spheres and planes are tested in place; a ray that passes a mesh's
@@ -882,7 +1001,7 @@ __device__ __forceinline__ int closest_loop(const DScene& S, const Ray& ray, boo
                 QuadHit q;
                 q.face = 0xFFFFFFFFu; q.t = 0; q.u = 0; q.v = 0;
                 if (PACKET == 2) {
-                    serve_traverse<false, COUNT>(S, m.root, need, ray, FLT_MAX, q, qs, wk);
+                    mesh_serve<false, COUNT>(S, m.root, need, ray, FLT_MAX, q, qs, wk);
                 } else if (PACKET) {
                     if (__ballot(need)) packet_traverse<false, COUNT>(S, m.root, need, ray, FLT_MAX, q, wk);
                 } else if (need) {
@@ -962,7 +1081,7 @@ __device__ __forceinline__ bool occluded_loop(const DScene& S, const Ray& ray, b
                 QuadHit q;
                 q.face = 0xFFFFFFFFu;
                 if (PACKET == 2) {
-                    serve_traverse<true, COUNT>(S, m.root, need, ray, ldist, q, qs, wk);
+                    mesh_serve<true, COUNT>(S, m.root, need, ray, ldist, q, qs, wk);
                 } else if (PACKET) {
                     if (__ballot(need)) packet_traverse<true, COUNT>(S, m.root, need, ray, ldist, q, wk, qs);
                 } else if (need) {
@@ -2200,7 +2319,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_intersect_lane(DScene S, int objec
             if (m.bb.w >= 0) need = alive && sphere_gate(m.bb, ray);
             QuadHit q;
             q.face = 0xFFFFFFFFu; q.t = 0; q.u = 0; q.v = 0;
-            if (PACKET == 2) serve_traverse<false, false>(S, m.root, need, ray, FLT_MAX, q, lds_stack, wk);
+            if (PACKET == 2) mesh_serve<false, false>(S, m.root, need, ray, FLT_MAX, q, lds_stack, wk);
             else if (__ballot(need)) packet_traverse<false, false>(S, m.root, need, ray, FLT_MAX, q, wk);
             if (need && q.face != 0xFFFFFFFFu) {
                 const float4* np = reinterpret_cast<const float4*>(S.normals + q.face);

@@ -1,0 +1,17 @@
+#!/bin/bash
+# the driver's short run (--steps 20 --warmup 5): how the 20 frames are cut into calls (frames per call, calls in flight)
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+run() { timeout -k 10 300 python bench.py --steps ${STEPS:-20} --warmup 5 "$@" --no-extras --no-cpu-baseline 2>/dev/null | python3 -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$*', '->', round(d['ms_per_step'],4), flush=True)" || exit 1; }
+for rep in 1 2; do
+run
+run --frames-in-flight 1 --batch-plan 20
+run --frames-in-flight 2 --batch-plan 20
+run --frames-in-flight 2 --batch-plan 16,4
+run --frames-in-flight 2 --batch-plan 14,6
+run --frames-in-flight 2 --batch-plan 12,8
+run --frames-in-flight 2 --batch-plan 4,16
+run --frames-in-flight 2 --batch-plan 6,14
+run --frames-in-flight 3 --batch-plan 10,6,4
+run --frames-in-flight 3 --batch-plan 8,8,4
+done
