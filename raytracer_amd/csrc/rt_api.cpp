@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cfloat>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -88,6 +89,14 @@ struct Knobs {
     int large_maxlv = -1;         // RT_LARGE_MAXLV: deepest level that may be "large"; -1 default
     int serve = -1;               // RT_SERVE: bounce levels by quad service: 0 never, 1 always, -1 by pass size
     int shade_serve_lv = 0;       // RT_SHADE_SERVE_LV: with packets below level 0, the light loops of large levels >= this one by quad service (0: packets)
+    // RT_SORT_SHADE: light loops that run as packets over levels >= 1 take their hits sorted by position (launch_sort_hits)
+    // from this many rays on; 0: never. MEASURED AND NOT USED (tools/r3_run11.sh, r3_run12.sh; same bytes): launches one at
+    // a time, the 8K field's level-1/2 light loops get a third faster (747 -> 679 ms of shadow packets over three frames,
+    // 36 ms of key and sort launches), but the frame, whose launches overlap, gets slower: 403 -> 430 ms with 8 bits per
+    // axis, 422 with 10, 440 with 6; 4K glass scene 27.2 -> 29.0. A wave's hits are then gathered from all over the pool
+    // (three 16-B reads and a write per hit, each its own cache line) next to closest-hit launches that wait for memory.
+    long long sort_shade = 0;
+    int sort_bits = 8;            // RT_SORT_BITS: bits per axis of the sort key (1..10)
     int split_small = 1;          // RT_SPLIT_SMALL: runs of small levels shaded per lane + resuming quads (1) / one quad launch (0)
     int tiny_run = 1024;          // RT_TINY_RUN: a run of at most this many hits is one quad launch
     long long tail = 8192;        // RT_TAIL: the levels that, with everything deeper, hold at most this many rays go to k_tail (0: never)
@@ -120,6 +129,8 @@ static Knobs knobs_from_env() {
     k.serve = int(env_ll("RT_SERVE", k.serve));
     k.split_small = int(env_ll("RT_SPLIT_SMALL", k.split_small));
     k.shade_serve_lv = int(env_ll("RT_SHADE_SERVE_LV", k.shade_serve_lv));
+    k.sort_shade = std::max(0ll, env_ll("RT_SORT_SHADE", k.sort_shade));
+    k.sort_bits = int(std::max(1ll, std::min(10ll, env_ll("RT_SORT_BITS", k.sort_bits))));
     k.tiny_run = int(std::max(0ll, env_ll("RT_TINY_RUN", k.tiny_run)));
     k.tail = std::max(0ll, env_ll("RT_TAIL", k.tail));
     k.index64 = std::getenv("RT_NO_FAST32") ? 1 : 0;
@@ -210,6 +221,11 @@ struct rt_scene {
     uint32_t host_turn = 0;
     void* noalloc_ws = nullptr;          // this device's copy of the file-scope `scratch` array (rt_render_device_noalloc)
     uint32_t pass_samples = 1u << 23;    // level-0 samples per pass (frames with more are cut into passes of whole pixels)
+    // sorted light loops (launch_sort_hits): one set of buffers per shade stream, grown on demand; the box of the meshes
+    struct SortBuf { uint32_t* keys[2] = {nullptr, nullptr}; uint32_t* vals[2] = {nullptr, nullptr}; void* temp = nullptr; size_t temp_bytes = 0; uint32_t cap = 0; };
+    SortBuf sort_buf[3];
+    SortBox sort_box{};
+    bool sort_box_ok = false;
 };
 #define RT_PASS_SAMPLES (s->pass_samples)
 #define RT_POOL_MAX_N0 std::max<uint32_t>(s->pass_samples, 1u << 23)   // a pool that overflowed on 64 pixels grows up to that of a default pass
@@ -220,6 +236,7 @@ static int free_scene(rt_scene* s) {
     for (void* p : s->owned) hipFree(p);
     hipFree(s->node_a); hipFree(s->node_b); hipFree(s->rays); hipFree(s->hit_n); hipFree(s->hit_p); hipFree(s->queue_e); hipFree(s->queue_s); hipFree(s->d_counters); hipFree(s->d_aa); hipFree(s->d_frame);
     hipFree(s->d_host_frames[0]); hipFree(s->d_host_frames[1]);
+    for (auto& b : s->sort_buf) { hipFree(b.keys[0]); hipFree(b.keys[1]); hipFree(b.vals[0]); hipFree(b.vals[1]); hipFree(b.temp); }
     for (int k = 0; k < 2; ++k) { if (s->ev_rendered[k]) hipEventDestroy(s->ev_rendered[k]); if (s->ev_copied[k]) hipEventDestroy(s->ev_copied[k]); }
     if (s->copy_stream) hipStreamDestroy(s->copy_stream);
     if (s->h_counters) hipHostFree(s->h_counters);
@@ -345,6 +362,26 @@ extern "C" int rt_scene_create_ex(const rt_flat_scene* sc, int device, uint32_t 
         std::memcpy(d.bb_center, sc->models[m].bb_center, sizeof d.bb_center);
         d.bb_radius = sc->models[m].bb_radius;
         d.pad = 0;
+    }
+    {   // the box the sorted light loops cut into cells: the models' bounding spheres, or their vertices where a model has none
+        float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        for (uint32_t m = 0; m < sc->n_models; ++m) {
+            const rt_model& md = sc->models[m];
+            if (md.bb_radius >= 0 && std::isfinite(md.bb_radius)) {
+                for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], md.bb_center[k] - md.bb_radius); hi[k] = std::max(hi[k], md.bb_center[k] + md.bb_radius); }
+            } else {
+                for (uint64_t f = md.first_face; f < uint64_t(md.first_face) + md.num_faces; ++f)
+                    for (const float* v : {sc->v0 + 3 * f, sc->v1 + 3 * f, sc->v2 + 3 * f})
+                        for (int k = 0; k < 3; ++k) { if (v[k] < lo[k]) lo[k] = v[k]; if (v[k] > hi[k]) hi[k] = v[k]; }
+            }
+        }
+        s->sort_box_ok = sc->n_models > 0;
+        for (int k = 0; k < 3; ++k) {
+            const float ext = hi[k] - lo[k];
+            if (!(ext > 0) || !std::isfinite(ext) || !std::isfinite(lo[k])) { s->sort_box_ok = false; break; }
+            s->sort_box.lo[k] = lo[k];
+            s->sort_box.scale[k] = 256.0f / ext;
+        }
     }
     std::vector<TriNormals> nrm(sc->n_faces);
     for (uint32_t f = 0; f < sc->n_faces; ++f) {
@@ -480,6 +517,8 @@ extern "C" int rt_scene_set_option(rt_scene* s, const char* name, int64_t value)
     else if (n == "serve") k.serve = value < 0 ? -1 : (value ? 1 : 0);
     else if (n == "split_small") k.split_small = value ? 1 : 0;
     else if (n == "shade_serve_level") k.shade_serve_lv = int(value);
+    else if (n == "sort_shade") k.sort_shade = std::max<int64_t>(0, value);
+    else if (n == "sort_bits") k.sort_bits = int(std::max<int64_t>(1, std::min<int64_t>(10, value)));
     else if (n == "tiny_run") k.tiny_run = int(std::max<int64_t>(0, std::min<int64_t>(value, 1 << 30)));
     else if (n == "tail_rays") k.tail = std::max<int64_t>(0, value);
     else if (n == "index64") k.index64 = value ? 1 : 0;
@@ -711,6 +750,33 @@ static uint32_t wide_grid_for(const rt_scene* s, uint32_t pass, int lo, int hi) 
     return uint32_t(std::min<uint64_t>(uint64_t(s->knobs.wide_grid), (n + n / 4u) / 64u + 2u * RT_SHARDS));
 }
 
+// Buffers of the sorted light loops for shade stream `which`, at least n_slots slots (grow-only). false: no memory - the
+// launch then walks the pool order.
+static bool ensure_sort_buf(rt_scene* s, int which, uint32_t n_slots) {
+    rt_scene::SortBuf& b = s->sort_buf[which];
+    if (b.cap >= n_slots) return true;
+    const uint32_t cap = std::max<uint32_t>(n_slots + n_slots / 4u, 1u << 16) & ~63u;
+    const size_t tb = sort_hits_temp_bytes(cap);
+    if (!tb) return false;
+    if (b.cap) (void)hipDeviceSynchronize();      // (a frame in flight may still read the old ones)
+    hipFree(b.keys[0]); hipFree(b.keys[1]); hipFree(b.vals[0]); hipFree(b.vals[1]); hipFree(b.temp);
+    b = rt_scene::SortBuf{};
+    bool ok = true;
+    for (int k = 0; k < 2; ++k) {
+        ok = ok && hipMalloc(reinterpret_cast<void**>(&b.keys[k]), size_t(cap) * 4u) == hipSuccess;
+        ok = ok && hipMalloc(reinterpret_cast<void**>(&b.vals[k]), size_t(cap) * 4u) == hipSuccess;
+    }
+    ok = ok && hipMalloc(&b.temp, tb) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        hipFree(b.keys[0]); hipFree(b.keys[1]); hipFree(b.vals[0]); hipFree(b.vals[1]); hipFree(b.temp);
+        b = rt_scene::SortBuf{};
+        return false;
+    }
+    b.temp_bytes = tb; b.cap = cap;
+    return true;
+}
+
 // Enqueue the passes covering pixels [px0, px0+npx) of the frame's pixel order, pass_px pixels at a time.
 // Records which PassCounters slot each pass used in `slots` (px0, npx, slot).
 //
@@ -812,8 +878,28 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
                 const uint32_t g = wide ? (B.level_hi == 0 ? grid0 : wide_grid)
                                    : (B.level_hi == 0 ? grid0q : (form == RT_FORM_QUAD_FRESH ? small_grid(s, slot, B.level, B.level_hi)
                                                                   : small_run ? resume_grid(s, slot, B.level) : 4u * RT_LEVEL_GRID));
+                // packets over a bounce level: the hits sorted by position first (k_sort_keys, radix sort), from knob sort_shade
+                // rays on and where the previous frame's count of this pass says how many slots to sort; a level that grew past
+                // the estimate is walked in pool order behind the sorted part. Never for the static pool (allocates).
+                uint32_t sort_slots = 0;
+                if (form == RT_FORM_WIDE && B.level >= 1 && s->d.packet >= 2 && s->knobs.sort_shade > 0 && s->sort_box_ok && !J.noalloc &&
+                    !s->knobs.use_graph) {
+                    uint64_t n = 0;
+                    for (int l = B.level; l <= B.level_hi; ++l) n += level_hint(s, slot, l);
+                    if (n >= uint64_t(s->knobs.sort_shade) && n < (1ull << 30)) {
+                        sort_slots = uint32_t(((n + n / 8u) / 64u + 2u * RT_SHARDS) * 64u);
+                        if (!ensure_sort_buf(s, which, sort_slots)) sort_slots = 0;
+                    }
+                }
                 const int rc2 = timed_launch(J, sb, form == RT_FORM_WIDE ? RT_K_SHADE_WIDE : form == RT_FORM_QUAD_PARKED ? RT_K_SHADE_PARKED : RT_K_SHADE_QUAD,
-                                             [&] { launch_shade(form, s->count_work, s->d, B, g, sb); });
+                                             [&] {
+                                                 if (sort_slots) {
+                                                     rt_scene::SortBuf& sbuf = s->sort_buf[which];
+                                                     B.perm = launch_sort_hits(s->d, B, s->sort_box, uint32_t(s->knobs.sort_bits), sbuf.keys, sbuf.vals, sbuf.temp, sbuf.temp_bytes, sort_slots, sb);
+                                                     B.perm_n = B.perm ? sort_slots : 0u;
+                                                 }
+                                                 launch_shade(form, s->count_work, s->d, B, g, sb);
+                                             });
                 if (rc2 != RT_OK) return rc2;
             }
             return RT_OK;

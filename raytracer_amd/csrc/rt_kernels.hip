@@ -22,6 +22,7 @@
 // contraction; the x86 reference build has none), correctly rounded f32 divide/sqrt (hipcc default), and double
 // exactly where the reference's overload resolution computes in double (sphere roots, pow, camera tan product).
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 #include <algorithm>
 #include <float.h>
 #include <stdint.h>
@@ -1810,23 +1811,39 @@ __device__ __forceinline__ void shade_wide_body(const DScene& S, const LevelArgs
     else if (RT_LOG_PTR(A.wave_log)) wk.t_start = wall_clock64();
     uint32_t n_shadow = 0;
     const uint32_t nwv = blockDim.x >> 6;      // see extend_wide_body
-    for (uint32_t grp = blockIdx.x * nwv + (threadIdx.x >> 6); grp < G.total; grp += gridDim.x * nwv) {
-        uint32_t shard, pos, lim;
-        locate(G, grp, shard, pos, lim);
-        const uint32_t i = pos + (threadIdx.x & 63u);
+    // Sorted light loops (packets over levels >= 1, A.perm): the first n_perm groups take their 64 hits from the
+    // permutation - neighbours in space, whose shadow rays towards a light travel together like those of camera rays' hits -
+    // instead of 64 consecutive pool entries, which after a bounce lie all over the scene. The permutation covers the
+    // first n_perm groups of the pool order (hits only); groups behind it (a level that grew past the host's estimate)
+    // are walked in pool order as ever.
+    const uint32_t n_perm = (PACKET == 1 && !level0 && A.perm) ? (A.perm_n >> 6) : 0u;
+    const uint32_t n_groups = G.total > n_perm ? G.total : n_perm;
+    for (uint32_t grp = blockIdx.x * nwv + (threadIdx.x >> 6); grp < n_groups; grp += gridDim.x * nwv) {
+        uint32_t shard = 0, pos = 0, lim = 0;
+        uint32_t i;
+        bool have;
+        if (PACKET == 1 && grp < n_perm) {                                                    // wave-uniform
+            const LevelArgs Af = reload_level_args();
+            i = Af.perm[grp * 64u + (threadIdx.x & 63u)];
+            have = i != 0xFFFFFFFFu;
+        } else {
+            locate(G, grp, shard, pos, lim);
+            i = pos + (threadIdx.x & 63u);
+            have = i < lim;
+        }
         uint4 b = make_uint4(0, 0, 0, 0);
         float4 hn = make_float4(0, 0, 0, 0), hp = make_float4(0, 0, 0, 0);
         bool hit;
         {
             const LevelArgs Af = (RT_RELOAD_FOR(PACKET)) ? reload_level_args() : A_;
-            if (i < lim) b = pool_ld(Af.node_b + i);
+            if (have) b = pool_ld(Af.node_b + i);
             hit = (b.w & (NODE_HIT | NODE_PARKED)) == NODE_HIT;
             if (!__any(hit)) continue;                                                       // wave-uniform
             if (hit) { hn = pool_ld(Af.hit_n + i); hp = pool_ld(Af.hit_p + i); }
         }
         int parked;
         shade_ray<false, COUNT, GPOW, PACKET>(S, A, i, b, hit, true, f4xyz(hn), f4xyz(hp), hp.w, hn.w, 0, 0, false, mk(0, 0, 0), lds, wk,
-                                n_shadow, parked, level0);      // the hits of camera rays: neighbours
+                                n_shadow, parked, level0 || n_perm != 0u);      // the hits of camera rays / sorted hits: neighbours
         const LevelArgs A = (RT_RELOAD_FOR(PACKET)) ? reload_level_args() : A_;
         if (level0) {       // mark; hit_n.w (tmpdist at the start of the light loop) is not needed again: keep the resume point there
             if (parked >= 0) { A.node_b[i].w = b.w | NODE_SPARKED; A.hit_n[i].w = __uint_as_float((uint32_t)parked); }
@@ -1945,6 +1962,55 @@ template <int MODE, bool COUNT, bool GPOW>
 __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WPE_SQ))) void k_shade_quad(DScene S, LevelArgs A) {
     __shared__ uint32_t lds_stack[RT_QSTACK * 16];
     shade_quad_body<MODE, COUNT, GPOW>(S, A, lds_stack, blockIdx.x, gridDim.x, false);
+}
+
+// ---- sorted light loops: the hits of a bounce level ordered by where they lie -------------------------------------
+// After a bounce the 64 consecutive pool entries a wave takes are hits all over the scene (the reflection rays of one
+// pixel's samples land on different objects), and their shadow rays as ONE packet are 64 unrelated traversals behind a
+// single chain of scalar fetches: the light loops of level 1 are the slowest launches of the 10 M-triangle field's frame
+// (350 of 896 serial ms). Shadow rays depend on nothing but the hit, so the hits may be shaded in any order: a 24-bit
+// Morton key of the hit point (axis_bits per axis over the box of the scene's meshes), a radix sort of (key, entry), and
+// k_shade_wide walks the sorted entry numbers (LevelArgs::perm) - a wave's hits are then neighbours in space and their
+// shadow rays towards a light travel together. Entries without a hit get no slot's worth of work (key past the valid
+// range, entry 0xFFFFFFFF). Results do not depend on the order: every hit is shaded exactly once, by the same code.
+__device__ __forceinline__ uint32_t spread10(uint32_t v) {      // bit k -> bit 3k (10 bits)
+    v &= 0x3FFu;
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+// axis_bits (1..10) bits per axis: the key has 3 * axis_bits bits, the all-ones key is "no hit"
+__global__ __launch_bounds__(256) void k_sort_keys(DScene S, LevelArgs A, SortBox bx, uint32_t axis_bits, uint32_t* __restrict__ keys,
+                                                   uint32_t* __restrict__ vals, uint32_t n_slots) {
+    const ShardView v = shard_view(A, A.level, A.level_hi);
+    const Groups G = make_groups<false>(v.start, v.cnt);
+    const uint32_t lane = threadIdx.x & 63u, nwv = blockDim.x >> 6;
+    const uint32_t none = (1u << (3u * axis_bits)) - 1u;
+    const float cells = (float)(1u << axis_bits), top = cells - 1.0f, down = cells * (1.0f / 256.0f);      // (SortBox::scale is for 256 cells)
+    for (uint32_t grp = blockIdx.x * nwv + (threadIdx.x >> 6); grp < (n_slots >> 6); grp += gridDim.x * nwv) {
+        uint32_t key = none, e = 0xFFFFFFFFu;
+        if (grp < G.total) {                                                                  // wave-uniform
+            uint32_t shard, pos, lim;
+            locate(G, grp, shard, pos, lim);
+            if (pos + lane < lim) {
+                const uint4 b = pool_ld(A.node_b + pos + lane);
+                if ((b.w & (NODE_HIT | NODE_PARKED)) == NODE_HIT) {
+                    const float4 p = pool_ld(A.hit_p + pos + lane);
+                    // (fmaxf / fminf return the non-NaN operand: a NaN coordinate lands in cell 0)
+                    const uint32_t cx = (uint32_t)fminf(fmaxf((p.x - bx.lo[0]) * bx.scale[0] * down, 0.0f), top);
+                    const uint32_t cy = (uint32_t)fminf(fmaxf((p.y - bx.lo[1]) * bx.scale[1] * down, 0.0f), top);
+                    const uint32_t cz = (uint32_t)fminf(fmaxf((p.z - bx.lo[2]) * bx.scale[2] * down, 0.0f), top);
+                    key = spread10(cx) | (spread10(cy) << 1) | (spread10(cz) << 2);      // (cells < 2^axis_bits: 3 * axis_bits key bits)
+                    if (key >= none) key = none - 1u;
+                    e = pos + lane;
+                }
+            }
+        }
+        keys[grp * 64u + lane] = key;
+        vals[grp * 64u + lane] = e;
+    }
 }
 
 // Colour of pool node i once its children (one level deeper) are final.
@@ -2447,6 +2513,20 @@ void launch_shade(int form, bool count, const DScene& S, const LevelArgs& A, uin
     dim3 g(grid), b(RT_BLOCK);
     if (S.generic_pow) { if (count) launch_shade_t<true, true>(form, S, A, g, b, st); else launch_shade_t<false, true>(form, S, A, g, b, st); }
     else { if (count) launch_shade_t<true, false>(form, S, A, g, b, st); else launch_shade_t<false, false>(form, S, A, g, b, st); }
+}
+size_t sort_hits_temp_bytes(uint32_t n_slots) {
+    size_t bytes = 0;
+    hipcub::DoubleBuffer<uint32_t> dk(nullptr, nullptr), dv(nullptr, nullptr);
+    if (hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, dk, dv, int(n_slots), 0, 30) != hipSuccess) return 0;
+    return bytes;
+}
+const uint32_t* launch_sort_hits(const DScene& S, const LevelArgs& A, const SortBox& box, uint32_t axis_bits, uint32_t* const keys[2],
+                                 uint32_t* const vals[2], void* temp, size_t temp_bytes, uint32_t n_slots, hipStream_t st) {
+    axis_bits = std::max(1u, std::min(10u, axis_bits));
+    hipLaunchKernelGGL(k_sort_keys, dim3(std::min<uint32_t>(2048u, (n_slots / 64u + 3u) / 4u)), dim3(256), 0, st, S, A, box, axis_bits, keys[0], vals[0], n_slots);
+    hipcub::DoubleBuffer<uint32_t> dk(keys[0], keys[1]), dv(vals[0], vals[1]);
+    if (hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, dk, dv, int(n_slots), 0, int(3u * axis_bits), st) != hipSuccess) return nullptr;
+    return dv.Current();
 }
 void launch_set_frame_params(const FrameParamsBatch& p, uint32_t n_frames, FrameParams* dst, void* clear, size_t clear_bytes, hipStream_t st) {
     const uint32_t n16 = uint32_t(clear_bytes / 16);

@@ -127,8 +127,20 @@ struct LevelArgs {
     uint32_t debug;              // timing experiments only (RT_DEBUG_SKIP)
     uint32_t chunk_log2;         // level-0 shard chunks (RT_SHARD_CHUNK_LOG2; RT_CHUNK_LOG2 in the environment for experiments)
     uint4* wave_log;             // diagnostics (COUNT builds, RT_WAVE_LOG): per workgroup {start, end, traversal ticks, batches}
+    const uint32_t* perm;        // k_shade_wide as packets over levels >= 1: the hits of the range sorted by position (launch_sort_hits),
+    uint32_t perm_n;             // perm_n slots (a multiple of 64; 0xFFFFFFFF = no entry); null: pool order
     PixelMap pm;
 };
+
+// Hits of levels A.level..A.level_hi (>= 1) sorted by the cell of their hit point (sorted light loops, rt_kernels.hip).
+// Slot d of the first n_slots slots of the range's dense enumeration (group d / 64 of the launch, lane d % 64) gets a
+// key; the sorted entry numbers are the permutation k_shade_wide walks instead of the pool order.
+struct SortBox { float lo[3]; float scale[3]; };      // cell (0..255 per axis) = (p - lo) * scale
+size_t sort_hits_temp_bytes(uint32_t n_slots);
+// keys[2], vals[2]: n_slots words each; returns the sorted entry numbers (one of vals[])
+// axis_bits (1..10): bits per axis of the Morton key
+const uint32_t* launch_sort_hits(const DScene& S, const LevelArgs& A, const SortBox& box, uint32_t axis_bits, uint32_t* const keys[2],
+                                 uint32_t* const vals[2], void* temp, size_t temp_bytes, uint32_t n_slots, hipStream_t st);
 
 struct UntileArgs {
     uint32_t W, H, tile_w, tile_h, tiles_x, n_tiles, n_parts;

@@ -386,6 +386,30 @@ def test_traversal_forms_agree(spp_grid):
     assert np.array_equal(default_img, base[0]) and st.trace_calls == base[1]
 
 
+@pytest.mark.parametrize("bits", [2, 8, 10])
+def test_sorted_light_loops_agree(bits):
+    """Option "sort_shade" (off by default: measured slower): the hits of a bounce level sorted by the cell of their hit point
+    before their shadow packets. Every hit is still shaded exactly once: same bytes and ray counts as the pool order, with
+    coarse and fine cells, on the second frame of a scene (the sort is sized by the previous frame's level sizes) and on a
+    deeper frame behind a shallow one (levels that outgrow the estimate are walked in pool order behind the sorted part)."""
+    fs = wl.scene_bunny(10, third="glass2")
+    cam, p16 = reference_camera(160, 120), Params(max_depth=6, aa=wl.aa_grid(4))
+    want, st_w = DeviceScene(fs).render(cam, p16)
+    dev = DeviceScene(fs)
+    dev.set_option("packet", 2)
+    dev.set_option("large_threshold", 0)       # every bounce level runs the per-lane kernels, i.e. as packets
+    dev.set_option("sort_shade", 1)
+    dev.set_option("sort_bits", bits)
+    dev.render(cam, Params(max_depth=2, aa=wl.aa_grid(4)))      # leaves hints for levels 0..2 only
+    for _ in range(2):
+        img, st = dev.render(cam, p16)
+        assert np.array_equal(img, want)
+        assert (st.trace_calls, st.shadow_rays, list(st.level_rays)) == (st_w.trace_calls, st_w.shadow_rays, list(st_w.level_rays))
+    small = reference_camera(64, 48)                              # far fewer hits than the estimate
+    img, st = dev.render(small, p16)
+    assert np.array_equal(img, DeviceScene(fs).render(small, p16)[0])
+
+
 def test_sphere_roots_exactly_zero(oracle_mod):
     """Sphere::intersect with both roots exactly 0 (reference src/primitives.cpp:188-192 takes neither branch and `dist`
     keeps the caller's value, defined as 0 at its first use here and in the oracle): a miss on the sphere, the plane
