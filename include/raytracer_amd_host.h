@@ -1,6 +1,7 @@
 /*
  * raytracer_amd_host.h — C view of the C++ host surface (raytracer_amd/host/raytracer.hpp) for non-C++
- * callers (the Python tests and bench.py bind these through ctypes). Host-only: none of these touch the GPU.
+ * callers (the Python tests and bench.py bind these through ctypes). Host-only: none of these touch the GPU, except
+ * rt_host_primitive_intersect, which says so.
  * Each entry point names the reference code whose result it reproduces bit for bit.
  */
 #ifndef RAYTRACER_AMD_HOST_H
@@ -64,6 +65,15 @@ typedef struct rt_host_scene rt_host_scene;
 int rt_host_scene_load_yaml(const char* fname, rt_host_scene** out);
 const rt_flat_scene* rt_host_scene_flat(const rt_host_scene* scene);
 void rt_host_scene_free(rt_host_scene* scene);
+
+/* Primitive::intersect and Primitive::getNormal (reference src/primitives.h:23-24, src/primitives.cpp:11-29, 42-81,
+ * 128-130, 173-203) called on ONE primitive of the host surface: kind 0 = Sphere, prm {cx, cy, cz, radius}; 1 = Plane,
+ * prm {nx, ny, nz, d} (the constructor normalises the normal); 2 = Triangle, prm {v0, v1, v2} (9 floats, flat normal).
+ * ray6 = origin, direction. The intersection RUNS ON THE DEVICE (the host surface's intersect() flattens the primitive
+ * into a one-object scene and calls rt_intersect): *hit_out 0/1, dist_out / normal_out (3 floats) as the reference's
+ * intersect() leaves them on a hit. getnormal_out (3 floats, may be NULL) = getNormal(point3) (host arithmetic). */
+int rt_host_primitive_intersect(int kind, const float* prm, const float* ray6, const float* point3, int* hit_out,
+                                float* dist_out, float* normal_out, float* getnormal_out);
 
 /* cv::imwrite(outFilename, img) of main() (reference src/raytracer.cpp:720) for the BGR8 frame rt_render fills:
  * .png (8-bit RGB, uncompressed deflate) or .ppm (P6). */

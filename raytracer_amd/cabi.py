@@ -124,6 +124,7 @@ HOST_EXPORTS = [
     "rt_host_camera_make", "rt_host_plane_make", "rt_host_mat3_rotation", "rt_host_bbvol", "rt_host_model_load_ply",
     "rt_host_model_from_arrays", "rt_host_model_transform", "rt_host_model_num_faces", "rt_host_model_get", "rt_host_model_free",
     "rt_host_known_answers", "rt_host_scene_load_yaml", "rt_host_scene_flat", "rt_host_scene_free", "rt_host_write_image",
+    "rt_host_primitive_intersect",
 ]
 
 _lib = None

@@ -42,6 +42,28 @@ int rt_host_plane_make(const float* normal, float dist, rt_plane* out) {
     return RT_OK;
 }
 
+int rt_host_primitive_intersect(int kind, const float* prm, const float* ray6, const float* point3, int* hit_out,
+                                float* dist_out, float* normal_out, float* getnormal_out) {
+    if (!prm || !ray6 || !hit_out || !dist_out || !normal_out || (getnormal_out && !point3)) { rt_set_error("rt_host_primitive_intersect: null argument"); return RT_ERR_INVALID; }
+    std::unique_ptr<Primitive> p;
+    if (kind == 0) p.reset(new Sphere(v3(prm), prm[3], Material()));
+    else if (kind == 1) p.reset(new Plane(v3(prm), prm[3], Material()));
+    else if (kind == 2) p.reset(new Triangle(v3(prm), v3(prm + 3), v3(prm + 6), Material()));
+    else { rt_set_error("rt_host_primitive_intersect: kind %d (0 sphere, 1 plane, 2 triangle)", kind); return RT_ERR_INVALID; }
+    try {
+        Float dist = 0;
+        Vec3f normal(0, 0, 0);
+        *hit_out = p->intersect(Ray(v3(ray6), v3(ray6 + 3)), dist, normal) ? 1 : 0;
+        *dist_out = dist;
+        put(normal_out, normal);
+        if (getnormal_out) put(getnormal_out, p->getNormal(v3(point3)));
+    } catch (const std::exception& e) {
+        rt_set_error("%s", e.what());
+        return RT_ERR_DEVICE;
+    }
+    return RT_OK;
+}
+
 int rt_host_mat3_rotation(float rx, float ry, float rz, float* out9) {
     if (!out9) { rt_set_error("rt_host_mat3_rotation: null argument"); return RT_ERR_INVALID; }
     const Mat3d m = Mat3d::rotation(rx, ry, rz);

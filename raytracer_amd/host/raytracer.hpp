@@ -233,13 +233,35 @@ public:
     }
 };
 
-// Base of everything renderable (ref src/primitives.h:18-28). intersect()/getNormal() are NOT part of
-// the host surface any more: they run on the device (rt_intersect is the C-ABI equivalent).
+// Base of everything renderable (ref src/primitives.h:18-28).
 struct Primitive {
     Material material;
     explicit Primitive(const Color& c) : material(c) {}
     explicit Primitive(Material m = Material()) : material(std::move(m)) {}
     virtual void flatten(FlatSceneBuilder& b) const = 0;
+    // ref src/primitives.h:23: ONE ray against THIS primitive - on the device, like every intersection here: the primitive
+    // is flattened into a one-object scene and rt_intersect is asked (a scene build and a launch per call: for the odd
+    // caller of the virtual; the renderer and rt_intersect on a whole Scene are the batch forms). Returns the reference's
+    // bool; `dist` and `normal` are what its intersect() computes on a hit and are left as they were on a miss.
+    // Throws on device errors.
+    bool intersect(const Ray& ray, Float& dist, Vec3f& normal) const {
+        FlatSceneBuilder fb;
+        flatten(fb);
+        const rt_flat_scene fs = fb.view();
+        rt_scene* dev = nullptr;
+        if (rt_scene_create(&fs, 0, &dev) != RT_OK) throw std::runtime_error(rt_last_error());
+        const float r6[6] = {ray.origin().x, ray.origin().y, ray.origin().z, ray.direction().x, ray.direction().y, ray.direction().z};
+        int32_t hit = -1;
+        float d = 0, n[3] = {0, 0, 0};
+        const int rc = rt_intersect(dev, 0, r6, 1, &hit, &d, n);
+        const std::string err = rc == RT_OK ? std::string() : std::string(rt_last_error());
+        rt_scene_destroy(dev);
+        if (rc != RT_OK) throw std::runtime_error(err);
+        if (hit < 0) return false;
+        dist = d; normal = Vec3f(n[0], n[1], n[2]);
+        return true;
+    }
+    virtual Vec3f getNormal(const Vec3f& vec) const = 0;      // ref src/primitives.h:24
     virtual ~Primitive() = default;
 };
 
@@ -249,6 +271,7 @@ struct Plane : Primitive {              // ref src/primitives.h:31-62: ax+by+cz+
     Plane(Float a_, Float b_, Float c_, Float d_, const Color& col) : Plane(a_, b_, c_, d_, Material(col)) {}
     Plane(Vec3f normal, Float dist, const Material& m) : Primitive(m), d(dist) { setNormal(normal); }
     Plane(const Vec3f& normal, Float dist, const Color& col) : Plane(normal, dist, Material(col)) {}
+    Vec3f getNormal(const Vec3f&) const override { return Vec3f(a, b, c); }                       // ref src/primitives.cpp:27-29
     void flatten(FlatSceneBuilder& fb) const override {
         rt_plane p; p.a = a; p.b = b; p.c = c; p.d = d;
         fb.planes.push_back(p);
@@ -264,6 +287,7 @@ struct Sphere : Primitive {             // ref src/primitives.h:107-119
     Sphere(const Vec3f& c, Float r, const Color& col) : Primitive(col), center(c), radius(r) {}
     Sphere(const Vec3f& c, Float r, const Material& m) : Primitive(m), center(c), radius(r) {}
     Sphere() : Sphere(Vec3f(0, 0, 0), 1, Material()) {}
+    Vec3f getNormal(const Vec3f& P) const override { Vec3f n(P - center); n /= radius; return n; }   // ref src/primitives.cpp:198-203
     void flatten(FlatSceneBuilder& fb) const override {
         rt_sphere s; s.center[0] = center.x; s.center[1] = center.y; s.center[2] = center.z; s.radius = radius;
         fb.spheres.push_back(s);
@@ -290,6 +314,7 @@ struct Triangle : Primitive {           // ref src/primitives.h:64-102
         n0.normalize();
         return n0;
     }
+    Vec3f getNormal(const Vec3f&) const override { return faceNormal; }          // ref src/primitives.cpp:128-130
     void scale(Float s) { v0 *= s; v1 *= s; v2 *= s; }                          // ref src/primitives.cpp:141-145
     Triangle& operator+=(const Vec3f& t) { v0 += t; v1 += t; v2 += t; return *this; }   // :154-159
     Triangle& operator*=(const Mat3d& m) { v0 *= m; v1 *= m; v2 *= m; n0 *= m; n1 *= m; n2 *= m; return *this; }  // :161-169
@@ -331,6 +356,7 @@ struct Model : Primitive {              // ref src/primitives.h:121-159
         }
         bbvol = Sphere(center, radius, Color(0));
     }
+    Vec3f getNormal(const Vec3f&) const override { return Vec3f(0, 0, 0); }                       // ref src/primitives.cpp:399-401 ("currently broken")
     Model& scale(Float s) { for (auto& f : faces) f.scale(s); updateBBVol(); return *this; }      // :386-393
     Model& translate(const Vec3f& t) { return *this += t; }
     Model& operator*=(const Mat3d& m) { for (auto& f : faces) f *= m; return *this; }             // :403-408 (bbvol NOT updated)

@@ -369,3 +369,57 @@ def test_host_async_batches_equal_device_frames():
     dev.render_batch_host_async(cams[1:3], p, pageable.ctypes.data, fb)
     dev.status()
     assert np.array_equal(pageable[0], singles[1]) and np.array_equal(pageable[1], singles[2])
+
+
+@pytest.mark.gpu
+def test_host_primitive_intersect_golden():
+    """Primitive::intersect / getNormal of the C++ host surface (reference src/primitives.h:23-24), which run ONE ray
+    against ONE primitive on the device (raytracer.hpp: a one-object scene + rt_intersect), against the reference's own
+    answers for the sphere, the plane and the lone triangle of tests/golden/intersect.npz: same bool, and on a hit the
+    same bits of dist and normal; getNormal against the reference's three-line bodies."""
+    import ctypes as C
+    from helpers import gold, same_bits
+    from raytracer_amd import cabi
+    from raytracer_amd.cabi import fptr
+    lib = cabi.load()
+    g = gold("intersect.npz")
+    rays = g["rays"]
+
+    def call(kind, prm, ray, point=None):
+        hit, dist = C.c_int(-7), C.c_float(0)
+        nrm, gn = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        pt = np.ascontiguousarray(point if point is not None else np.zeros(3), np.float32)
+        cabi.check(lib, lib.rt_host_primitive_intersect(kind, fptr(np.ascontiguousarray(prm, np.float32)), fptr(np.ascontiguousarray(ray)),
+                                                        fptr(pt), C.byref(hit), C.byref(dist), fptr(nrm), fptr(gn)))
+        return hit.value, np.float32(dist.value), nrm, gn
+
+    def pick(hits, n=24):
+        yes, no = np.flatnonzero(hits)[:n], np.flatnonzero(~hits)[:n]
+        assert len(yes) and len(no)
+        return list(yes) + list(no)
+
+    sphere, plane = g["scene_spheres"][0], g["scene_planes"][0]            # objects 0 and 4 of the golden scene
+    for kind, prm, obj in ((0, sphere, 0), (1, plane, 4)):
+        for i in pick(g[f"hit_{obj}"] >= 0):
+            hit, d, n, _ = call(kind, prm, rays[i])
+            assert hit == int(g[f"hit_{obj}"][i] >= 0), (kind, i)
+            if hit:
+                assert same_bits(d, g[f"dist_{obj}"][i]) and same_bits(n, g[f"normal_{obj}"][i]), (kind, i)
+    tri = np.concatenate([g["lone_v0"][0], g["lone_v1"][0], g["lone_v2"][0]])
+    e1, e2 = g["lone_v1"][0] - g["lone_v0"][0], g["lone_v2"][0] - g["lone_v0"][0]
+    flat = np.cross(e1 / np.linalg.norm(e1), e2 / np.linalg.norm(e2))
+    flat = (flat / np.linalg.norm(flat)).astype(np.float32)
+    for i in list(np.flatnonzero(g["lone_hit"] == 0)[:24]) + list(np.flatnonzero(g["lone_hit"] < 0)[:24]):
+        hit, d, n, _ = call(2, tri, rays[i])
+        assert hit == int(g["lone_hit"][i] == 0), i
+        if hit:       # (the golden triangle carries per-vertex normals, this one the flat normal of the 3-vertex constructor)
+            assert same_bits(d, g["lone_dist"][i]) and np.allclose(n, flat, atol=2e-6), i
+    # getNormal: Sphere (P - c) * float(1.0 / r) (src/primitives.cpp:198-203, container.h:72-75), Plane (a, b, c), Triangle faceNormal
+    P = np.array([0.3, -0.2, -7.1], np.float32)
+    _, _, _, gn = call(0, sphere, rays[0], P)
+    assert same_bits(gn, (P - sphere[:3]) * np.float32(1.0 / np.float64(sphere[3])))
+    _, _, _, gn = call(1, plane, rays[0], P)
+    assert same_bits(gn, plane[:3])
+    _, _, _, gn = call(2, tri, rays[0], P)
+    assert np.allclose(gn, flat, atol=2e-6)                                  # the flat face normal the 3-vertex constructor computes
+    assert lib.rt_host_primitive_intersect(9, fptr(sphere), fptr(rays[0]), None, C.byref(C.c_int()), C.byref(C.c_float()), fptr(np.zeros(3, np.float32)), None) != 0
