@@ -354,6 +354,11 @@ int rt_scene_set_pass_samples(rt_scene* scene, uint32_t samples);
  *   "index64"          1: sample-index arithmetic by 64-bit division even where 32 bits would do
  *   "chunk_log2"       level-0 blocks per shard chunk
  *   "graph"            1: asynchronous frames are captured into a hipGraph and replayed (measured slower)
+ *   "shade_serve_level" with packets below level 0: the light loops of large levels >= this one by quad service instead of
+ *                      packets (0, default: packets; measured slower)
+ *   "sort_shade"       light loops that run as packets over a bounce level take that level's hits sorted by the cell of
+ *                      their hit point (Morton key + radix sort) from this many rays on (0, default: never; measured slower)
+ *   "sort_bits"        bits per axis of that key (1..10, default 8)
  * The environment variables of the same meaning (RT_PACKET, RT_LARGE_THR, ... tools/exp_*.sh) are read once, by
  * rt_scene_create; no rendering call reads the environment. Unknown name or value out of range: RT_ERR_INVALID. */
 int rt_scene_set_option(rt_scene* scene, const char* name, int64_t value);

@@ -408,6 +408,14 @@ def test_sorted_light_loops_agree(bits):
     small = reference_camera(64, 48)                              # far fewer hits than the estimate
     img, st = dev.render(small, p16)
     assert np.array_equal(img, DeviceScene(fs).render(small, p16)[0])
+    if bits == 8:       # option "shade_serve_level" (off by default too): those light loops by quad service instead of packets
+        dev2 = DeviceScene(fs)
+        dev2.set_option("packet", 2)
+        dev2.set_option("large_threshold", 0)
+        dev2.set_option("shade_serve_level", 1)
+        dev2.render(cam, p16)
+        img, st = dev2.render(cam, p16)
+        assert np.array_equal(img, want) and (st.trace_calls, st.shadow_rays) == (st_w.trace_calls, st_w.shadow_rays)
 
 
 def test_sphere_roots_exactly_zero(oracle_mod):
