@@ -252,7 +252,7 @@ def main():
     # ranks, the exchange of one call - gather, untile - the rendering of the other) whatever --steps is
     # (one GPU: the fewest calls of at most 32 frames, evenly sized - a short run is better off as ONE large call than as
     # one small call per slot: --steps 20 as 2 x 10 0.240-0.244 ms per frame, as 1 x 20 0.235, tools/exp_steps20b.sh)
-    per_call = args.steps // in_flight if multi else -(-args.steps // -(-args.steps // 32))
+    per_call = args.steps // in_flight if multi else -(-args.steps // max(1, -(-args.steps // 32)))
     B = max(1, min(32, args.frames_per_batch, args.batch_samples // max(1, (W * H * params.spp) // world), per_call))
     plan = [int(x) for x in args.batch_plan.split(",") if x]
     if plan:
