@@ -97,6 +97,8 @@ struct Knobs {
     // (three 16-B reads and a write per hit, each its own cache line) next to closest-hit launches that wait for memory.
     long long sort_shade = 0;
     int sort_bits = 8;            // RT_SORT_BITS: bits per axis of the sort key (1..10)
+    int order0 = 1;               // RT_ORDER0: level-0 launches of a small one-pass frame hand out their groups in descending order of the
+                                  // previous frame's cost (k_order_groups); 0: pool order
     int split_small = 1;          // RT_SPLIT_SMALL: runs of small levels shaded per lane + resuming quads (1) / one quad launch (0)
     int tiny_run = 1024;          // RT_TINY_RUN: a run of at most this many hits is one quad launch
     long long tail = 8192;        // RT_TAIL: the levels that, with everything deeper, hold at most this many rays go to k_tail (0: never)
@@ -128,6 +130,7 @@ static Knobs knobs_from_env() {
     k.large_maxlv = int(env_ll("RT_LARGE_MAXLV", k.large_maxlv));
     k.serve = int(env_ll("RT_SERVE", k.serve));
     k.split_small = int(env_ll("RT_SPLIT_SMALL", k.split_small));
+    k.order0 = int(env_ll("RT_ORDER0", k.order0)) ? 1 : 0;
     k.shade_serve_lv = int(env_ll("RT_SHADE_SERVE_LV", k.shade_serve_lv));
     k.sort_shade = std::max(0ll, env_ll("RT_SORT_SHADE", k.sort_shade));
     k.sort_bits = int(std::max(1ll, std::min(10ll, env_ll("RT_SORT_BITS", k.sort_bits))));
@@ -224,6 +227,14 @@ struct rt_scene {
     // sorted light loops (launch_sort_hits): one set of buffers per shade stream, grown on demand; the box of the meshes
     struct SortBuf { uint32_t* keys[2] = {nullptr, nullptr}; uint32_t* vals[2] = {nullptr, nullptr}; void* temp = nullptr; size_t temp_bytes = 0; uint32_t cap = 0; };
     SortBuf sort_buf[3];
+    // expensive groups first (k_order_groups): per-group cost of the level-0 closest-hit [0] and light-loop [1] launch of the
+    // most recent small one-pass frame, and the group numbers in descending order of it for the next one
+    uint32_t* cost0[2] = {nullptr, nullptr};
+    uint32_t* order0[2] = {nullptr, nullptr};
+    uint32_t order_cap = 0;              // groups the four arrays hold
+    uint32_t order_n = 0;                // groups the current order was made for (0: none yet)
+    hipEvent_t ev_ordered = nullptr;     // recorded behind k_order_groups; the next frame asks whether it has happened
+    bool order_pending = false;
     SortBox sort_box{};
     bool sort_box_ok = false;
 };
@@ -236,6 +247,8 @@ static int free_scene(rt_scene* s) {
     for (void* p : s->owned) hipFree(p);
     hipFree(s->node_a); hipFree(s->node_b); hipFree(s->rays); hipFree(s->hit_n); hipFree(s->hit_p); hipFree(s->queue_e); hipFree(s->queue_s); hipFree(s->d_counters); hipFree(s->d_aa); hipFree(s->d_frame);
     hipFree(s->d_host_frames[0]); hipFree(s->d_host_frames[1]);
+    hipFree(s->cost0[0]); hipFree(s->cost0[1]); hipFree(s->order0[0]); hipFree(s->order0[1]);
+    if (s->ev_ordered) hipEventDestroy(s->ev_ordered);
     for (auto& b : s->sort_buf) { hipFree(b.keys[0]); hipFree(b.keys[1]); hipFree(b.vals[0]); hipFree(b.vals[1]); hipFree(b.temp); }
     for (int k = 0; k < 2; ++k) { if (s->ev_rendered[k]) hipEventDestroy(s->ev_rendered[k]); if (s->ev_copied[k]) hipEventDestroy(s->ev_copied[k]); }
     if (s->copy_stream) hipStreamDestroy(s->copy_stream);
@@ -516,6 +529,7 @@ extern "C" int rt_scene_set_option(rt_scene* s, const char* name, int64_t value)
     else if (n == "large_max_level") k.large_maxlv = value < 0 ? -1 : int(std::min<int64_t>(value, RT_MAX_LEVELS));
     else if (n == "serve") k.serve = value < 0 ? -1 : (value ? 1 : 0);
     else if (n == "split_small") k.split_small = value ? 1 : 0;
+    else if (n == "order0") { k.order0 = value ? 1 : 0; s->order_n = 0; }
     else if (n == "shade_serve_level") k.shade_serve_lv = int(value);
     else if (n == "sort_shade") k.sort_shade = std::max<int64_t>(0, value);
     else if (n == "sort_bits") k.sort_bits = int(std::max<int64_t>(1, std::min<int64_t>(10, value)));
@@ -750,6 +764,29 @@ static uint32_t wide_grid_for(const rt_scene* s, uint32_t pass, int lo, int hi) 
     return uint32_t(std::min<uint64_t>(uint64_t(s->knobs.wide_grid), (n + n / 4u) / 64u + 2u * RT_SHARDS));
 }
 
+// Arrays of the expensive-groups-first order for at least n groups (grow-only). false: no memory - pool order then.
+static bool ensure_order_buf(rt_scene* s, uint32_t n, hipStream_t st) {
+    if (s->order_cap >= n && s->ev_ordered) return true;
+    if (s->order_cap) (void)hipDeviceSynchronize();      // (a frame in flight may still use the old ones)
+    for (int k = 0; k < 2; ++k) { hipFree(s->cost0[k]); hipFree(s->order0[k]); s->cost0[k] = s->order0[k] = nullptr; }
+    s->order_cap = 0; s->order_n = 0; s->order_pending = false;
+    const uint32_t cap = std::max<uint32_t>(n, 1u << 15);
+    bool ok = s->ev_ordered || hipEventCreateWithFlags(&s->ev_ordered, hipEventDisableTiming) == hipSuccess;
+    for (int k = 0; k < 2; ++k) {      // (costs: 4 words per group, cleared once here and then by k_order_groups)
+        ok = ok && hipMalloc(reinterpret_cast<void**>(&s->cost0[k]), size_t(cap) * 16u) == hipSuccess;
+        // (on the frame's stream: a plain hipMemset runs on the null stream, which the scene's non-blocking streams do not wait for)
+        ok = ok && hipMemsetAsync(s->cost0[k], 0, size_t(cap) * 16u, st) == hipSuccess;
+        ok = ok && hipMalloc(reinterpret_cast<void**>(&s->order0[k]), size_t(RT_ORDER_SLOTS(cap)) * 4u + cap) == hipSuccess;      // + k_order_groups' keys
+    }
+    if (!ok) {
+        (void)hipGetLastError();
+        for (int k = 0; k < 2; ++k) { hipFree(s->cost0[k]); hipFree(s->order0[k]); s->cost0[k] = s->order0[k] = nullptr; }
+        return false;
+    }
+    s->order_cap = cap;
+    return true;
+}
+
 // Buffers of the sorted light loops for shade stream `which`, at least n_slots slots (grow-only). false: no memory - the
 // launch then walks the pool order.
 static bool ensure_sort_buf(rt_scene* s, int which, uint32_t n_slots) {
@@ -833,6 +870,21 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
         uint32_t grid0 = (A.n0 + RT_BLOCK - 1) / RT_BLOCK;
         if (s->knobs.grid0) grid0 = std::min<uint32_t>(grid0, uint32_t(s->knobs.grid0));      // experiments
         const uint32_t grid0q = std::min<uint32_t>((A.n0 + 15) / 16, 4u * RT_LEVEL_GRID);
+        // Expensive groups first (k_order_groups): a frame that is ONE pass of a few thousand to RT_ORDER_MAX_GROUPS 64-sample
+        // groups - where a level-0 launch is mostly the drain of its longest waves - hands the groups out in descending order
+        // of what they cost in the scene's previous frame of the same size. Not for the static pool (allocates) or a graph.
+        const uint32_t n_grp0 = (A.n0 + 63u) / 64u;
+        bool order_on = s->knobs.order0 && px0 == 0 && done == 0 && npx <= pass_px && n_grp0 >= 2048u && n_grp0 <= RT_ORDER_MAX_GROUPS &&
+                        s->knobs.grid0 == 0 && !J.noalloc && !s->knobs.use_graph && ensure_order_buf(s, n_grp0, sa);
+        const uint32_t* order_e = nullptr;
+        const uint32_t* order_s = nullptr;
+        if (order_on && s->order_pending) {
+            // the previous frame's k_order_groups is not part of what that frame waits for: when it has not finished yet (a frame
+            // whose level-0 light loops are the last thing it does), this frame neither waits for it nor touches its arrays
+            if (hipEventQuery(s->ev_ordered) == hipSuccess) s->order_pending = false;
+            else { (void)hipGetLastError(); order_on = false; }
+        }
+        if (order_on && s->order_n == n_grp0) { order_e = s->order0[0]; order_s = s->order0[1]; }
         int rc;
         bool used_shade[3] = {false, false, false};
         // a shade stream waits for an event once per RECORDING of it: slots are re-recorded within a pass (ev_sync[2*lv]
@@ -872,10 +924,11 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
                 LevelArgs B = A;
                 B.level = part == 0 ? 0 : (lo == 0 && hi > 0 ? 1 : lo);
                 B.level_hi = part == 0 ? 0 : hi;
+                if (order_on && B.level_hi == 0 && form == RT_FORM_WIDE) { B.order0 = order_s; B.cost0 = s->cost0[1]; }
                 B.wave_log = (log_shade && B.level == log_level) ? wave_log : nullptr;
                 const bool wide = form == RT_FORM_WIDE || form == RT_FORM_WIDE_SERVE;
                 const uint32_t wide_grid = wide ? wide_grid_for(s, slot, B.level, B.level_hi) : RT_LEVEL_GRID;
-                const uint32_t g = wide ? (B.level_hi == 0 ? grid0 : wide_grid)
+                const uint32_t g = wide ? (B.level_hi == 0 ? (B.order0 ? RT_ORDER_SLOTS(grid0) : grid0) : wide_grid)
                                    : (B.level_hi == 0 ? grid0q : (form == RT_FORM_QUAD_FRESH ? small_grid(s, slot, B.level, B.level_hi)
                                                                   : small_run ? resume_grid(s, slot, B.level) : 4u * RT_LEVEL_GRID));
                 // packets over a bounce level: the hits sorted by position first (k_sort_keys, radix sort), from knob sort_shade
@@ -959,6 +1012,7 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
             }
             LevelArgs B = A;
             B.level = lv; B.level_hi = lv;
+            if (order_on && lv == 0) { B.order0 = order_e; B.cost0 = s->cost0[0]; }
             const int src = lv == 0 ? 0 : 1;
             const bool large = !meshes || lv == 0 || expect_large(s, slot, lv, lv);
             B.wave_log = (lv == log_level && !log_shade) ? wave_log : nullptr;
@@ -968,7 +1022,7 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
                     if ((rc = shade_small(small_lo, lv - 1, 2 * lv)) != RT_OK) return rc;
                     small_lo = -1;
                 }
-                if ((rc = timed_launch(J, sa, RT_K_EXTEND_WIDE, [&] { launch_extend(src, RT_FORM_WIDE, s->count_work, s->d, B, lv == 0 ? grid0 : wide_grid_for(s, slot, lv, lv), sa); })) != RT_OK) return rc;
+                if ((rc = timed_launch(J, sa, RT_K_EXTEND_WIDE, [&] { launch_extend(src, RT_FORM_WIDE, s->count_work, s->d, B, lv == 0 ? (B.order0 ? RT_ORDER_SLOTS(grid0) : grid0) : wide_grid_for(s, slot, lv, lv), sa); })) != RT_OK) return rc;
                 if (overlap) HIP_TRY(record(2 * lv));
                 // level 0 of a packet scene: the per-lane kernels traverse the meshes themselves, nothing is suspended
                 const bool quads = meshes && !((lv == 0 && s->d.packet) || s->d.packet >= 2);
@@ -1022,6 +1076,19 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
                 HIP_TRY(hipEventRecord(s->ev_sync[2 * RT_MAX_LEVELS + 1 + k], s->shade_stream[k]));
                 HIP_TRY(hipStreamWaitEvent(sa, s->ev_sync[2 * RT_MAX_LEVELS + 1 + k], 0));
             }
+        if (order_on) {
+            // behind level 0's light loops on their stream, NOT part of the join above: the frame does not wait for it. (At most
+            // 65,536 groups: ~10 us, over long before the next frame's light loops, which queue behind it, can start. On a
+            // stream of its own - a fifth per scene - one frame at a time got slower, 0.555 -> 0.567 ms: the streams share
+            // four hardware queues.)
+            hipStream_t so = overlap ? s->shade_stream[0] : sa;
+            launch_order_groups(s->cost0[0], s->cost0[1], s->order0[0], s->order0[1],
+                                reinterpret_cast<uint8_t*>(s->order0[0] + RT_ORDER_SLOTS(s->order_cap)),
+                                reinterpret_cast<uint8_t*>(s->order0[1] + RT_ORDER_SLOTS(s->order_cap)), n_grp0, so);
+            HIP_TRY(hipEventRecord(s->ev_ordered, so));
+            s->order_pending = true;
+            s->order_n = n_grp0;
+        }
         // (folding the deep levels, which hold few nodes, by ONE workgroup in one launch was measured again with the sharded
         // pool: 85 us against 9 launches x 5 us, 0.706 vs 0.686 ms/frame)
         const int fold_hi = std::min(levels, lv_tail) - 1;      // (the tail's levels are folded as subtrees)

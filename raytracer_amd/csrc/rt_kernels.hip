@@ -1592,11 +1592,19 @@ __device__ __forceinline__ void extend_wide_body(const DScene& S, const LevelArg
     // a workgroup is 1..4 independent waves (RT_WIDE_BLOCK: the dispatcher starts workgroups at a limited rate, and these
     // waves are short-lived), wave w of workgroup b takes groups b * waves + w, ...
     const uint32_t nwv = blockDim.x >> 6;
-    for (uint32_t grp = blockIdx.x * nwv + (threadIdx.x >> 6); grp < G.total; grp += gridDim.x * nwv) {
+    const bool ordered = level0 && A.order0;      // (wave-uniform)
+    const uint32_t n_w = ordered ? RT_ORDER_SLOTS(G.total) : G.total;
+    for (uint32_t w = blockIdx.x * nwv + (threadIdx.x >> 6); w < n_w; w += gridDim.x * nwv) {
+        // (level 0 of a small frame: the groups in descending order of last frame's cost, the dearest in parts: k_order_groups)
+        const uint32_t code = ordered ? ((const RT_CONSTANT uint32_t*)(const void*)A.order0)[w] : w;
+        if (code == RT_ORDER_NONE) continue;                                                   // wave-uniform
+        const uint32_t grp = ordered ? (code & 0x0FFFFFFFu) : code, parts_log2 = ordered ? ((code >> 28) & 3u) : 0u, part = ordered ? (code >> 30) : 0u;
+        if (grp >= G.total) continue;                                                          // (an order is only ever a hint: never out of range)
+        const unsigned long long t_grp = (level0 && A.cost0) ? wall_clock64() : 0ull;
         uint32_t shard, pos, lim;
         locate(G, grp, shard, pos, lim);
         const uint32_t i = pos + (threadIdx.x & 63u);
-        const bool active = i < lim;
+        const bool active = i < lim && ((threadIdx.x & 63u) >> (6u - parts_log2)) == part;
         Ray ray;
         ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 0);
         bool valid;
@@ -1622,6 +1630,8 @@ __device__ __forceinline__ void extend_wide_body(const DScene& S, const LevelArg
         }
         extend_finish(S, A, i, active && !parked, valid && !parked, true, ray, h, lane_read(next_base_l, shard),
                       A.n0 + (shard + 1u) * A.sub_cap, sc->level + (A.level + 1), 0u, A.level);
+        if (level0 && A.cost0 && lane_id() == 0)      // (the word of the wave's first quarter; a group that was not split: word 0)
+            A.cost0[4u * grp + (part << (2u - parts_log2))] = (uint32_t)min(wall_clock64() - t_grp, 0xFFFFull);
     }
     if (COUNT) {
         const uint32_t steps = wave_sum(wk.wave_nodes + wk.wave_tris);
@@ -1818,7 +1828,16 @@ __device__ __forceinline__ void shade_wide_body(const DScene& S, const LevelArgs
     // are walked in pool order as ever.
     const uint32_t n_perm = (PACKET == 1 && !level0 && A.perm) ? (A.perm_n >> 6) : 0u;
     const uint32_t n_groups = G.total > n_perm ? G.total : n_perm;
-    for (uint32_t grp = blockIdx.x * nwv + (threadIdx.x >> 6); grp < n_groups; grp += gridDim.x * nwv) {
+    const bool ordered = level0 && A.order0;      // (wave-uniform)
+    const uint32_t n_w = ordered ? RT_ORDER_SLOTS(n_groups) : n_groups;
+    for (uint32_t w = blockIdx.x * nwv + (threadIdx.x >> 6); w < n_w; w += gridDim.x * nwv) {
+        // (level 0 of a small frame: the groups in descending order of last frame's cost, the dearest in parts: k_order_groups)
+        const uint32_t code = ordered ? ((const RT_CONSTANT uint32_t*)(const void*)A.order0)[w] : w;
+        if (code == RT_ORDER_NONE) continue;                                                   // wave-uniform
+        const uint32_t grp = ordered ? (code & 0x0FFFFFFFu) : code, parts_log2 = ordered ? ((code >> 28) & 3u) : 0u, part = ordered ? (code >> 30) : 0u;
+        if (ordered && grp >= n_groups) continue;                                              // (an order is only ever a hint: never out of range)
+        const uint32_t cost_word = 4u * grp + (part << (2u - parts_log2));
+        const unsigned long long t_grp = (level0 && A.cost0) ? wall_clock64() : 0ull;
         uint32_t shard = 0, pos = 0, lim = 0;
         uint32_t i;
         bool have;
@@ -1829,7 +1848,7 @@ __device__ __forceinline__ void shade_wide_body(const DScene& S, const LevelArgs
         } else {
             locate(G, grp, shard, pos, lim);
             i = pos + (threadIdx.x & 63u);
-            have = i < lim;
+            have = i < lim && ((threadIdx.x & 63u) >> (6u - parts_log2)) == part;
         }
         uint4 b = make_uint4(0, 0, 0, 0);
         float4 hn = make_float4(0, 0, 0, 0), hp = make_float4(0, 0, 0, 0);
@@ -1838,13 +1857,17 @@ __device__ __forceinline__ void shade_wide_body(const DScene& S, const LevelArgs
             const LevelArgs Af = (RT_RELOAD_FOR(PACKET)) ? reload_level_args() : A_;
             if (have) b = pool_ld(Af.node_b + i);
             hit = (b.w & (NODE_HIT | NODE_PARKED)) == NODE_HIT;
-            if (!__any(hit)) continue;                                                       // wave-uniform
+            if (!__any(hit)) {                                                               // wave-uniform
+                if (level0 && Af.cost0 && lane_id() == 0) Af.cost0[cost_word] = 0u;
+                continue;
+            }
             if (hit) { hn = pool_ld(Af.hit_n + i); hp = pool_ld(Af.hit_p + i); }
         }
         int parked;
         shade_ray<false, COUNT, GPOW, PACKET>(S, A, i, b, hit, true, f4xyz(hn), f4xyz(hp), hp.w, hn.w, 0, 0, false, mk(0, 0, 0), lds, wk,
                                 n_shadow, parked, level0 || n_perm != 0u);      // the hits of camera rays / sorted hits: neighbours
         const LevelArgs A = (RT_RELOAD_FOR(PACKET)) ? reload_level_args() : A_;
+        if (level0 && A.cost0 && lane_id() == 0) A.cost0[cost_word] = (uint32_t)min(wall_clock64() - t_grp, 0xFFFFull);
         if (level0) {       // mark; hit_n.w (tmpdist at the start of the light loop) is not needed again: keep the resume point there
             if (parked >= 0) { A.node_b[i].w = b.w | NODE_SPARKED; A.hit_n[i].w = __uint_as_float((uint32_t)parked); }
         } else {
@@ -1962,6 +1985,107 @@ template <int MODE, bool COUNT, bool GPOW>
 __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WPE_SQ))) void k_shade_quad(DScene S, LevelArgs A) {
     __shared__ uint32_t lds_stack[RT_QSTACK * 16];
     shade_quad_body<MODE, COUNT, GPOW>(S, A, lds_stack, blockIdx.x, gridDim.x, false);
+}
+
+// ---- expensive groups first, the most expensive in parts -------------------------------------------------------------
+// A level-0 launch over ONE small frame is mostly drain: every wave of a 1080p frame has STARTED a third of the way into
+// the closest-hit launch, and the rest of it is the chip emptying while the packets that cross the mesh - ten times the
+// average wave's life - finish (tools/exp_wavelog2.py: 32,400 waves, mean life 9 us, longest 89 us, last start at 39 us
+// of 116). Their groups come wherever the picture has them. So every wave leaves behind how long its group took
+// (LevelArgs::cost0), one workgroup orders the group numbers (256 cost buckets of 0.64 us), and the next frame's launch
+// of the same kind hands the groups out in that order (LevelArgs::order0):
+//   * the expensive eighth (whole buckets, the most expensive first) goes to the front, the rest follows IN POOL ORDER - the
+//     long waves start first, the short ones fill in behind them, and the bulk of the launch keeps walking the pool as it
+//     lies (a frame whose groups all cost the same is left alone);
+//   * with the long waves first a launch is as long as its longest wave (89 us of closest hits, 139 us of light loops,
+//     on a chip that has been empty for half of that), so the most expensive groups are worked on in PARTS by several
+//     waves: the top 1/128 as four quarters (4x4 pixels each), up to the top 1/32 as two halves. A part's packet visits
+//     what its own rays visit: a wave of 16 rays executes fewer steps than the wave of 64 did.
+// Only WHICH wave works on WHICH entries, and when, changes - pool positions, shards and results do not - and a stale or
+// missing order (first frame, camera cut) costs time, never pixels. The costs are cleared here for the next frame (a wave
+// writes the word of its first quarter; a group's cost is the sum of its four words).
+__global__ __launch_bounds__(1024) void k_order_groups(uint32_t* __restrict__ cost_e, uint32_t* __restrict__ cost_s,
+                                                       uint32_t* __restrict__ order_e, uint32_t* __restrict__ order_s,
+                                                       uint8_t* __restrict__ key_e, uint8_t* __restrict__ key_s, uint32_t n) {
+    __shared__ uint32_t bins[256];
+    __shared__ uint32_t scan[1024];
+    __shared__ uint32_t s_q, s_h, s_thr, s_front;
+    uint32_t* cost = blockIdx.x == 0 ? cost_e : cost_s;
+    uint32_t* order = blockIdx.x == 0 ? order_e : order_s;
+    const uint32_t t = threadIdx.x;
+    // every group's key is formed ONCE and kept (n bytes): whatever the costs hold, or did while this ran, every group lands
+    // in the order exactly once
+    uint8_t* keys = blockIdx.x == 0 ? key_e : key_s;
+    const uint4* cost4 = reinterpret_cast<const uint4*>(cost);
+    auto key_of = [&](uint32_t g) { return (uint32_t)keys[g]; };      // 0 = the most expensive bucket
+    if (t < 256u) bins[t] = 0u;
+    __syncthreads();
+    for (uint32_t g = t; g < n; g += 1024u) {
+        const uint4 c = cost4[g];
+        const uint32_t key = 255u - min((c.x + c.y + c.z + c.w) >> 6, 255u);
+        keys[g] = (uint8_t)key;
+        atomicAdd(&bins[key], 1u);
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (t == 0) {
+        // keys < q: quarters; < h: halves; < thr: whole, in front. bins[] becomes each front bucket's first SLOT.
+        uint32_t groups = 0, slots = 0, q = 0, h = 0, thr = 0;
+        bool open_q = true, open_h = true, open = true;
+        for (uint32_t b = 0; b < 256u; ++b) {
+            const uint32_t c = bins[b];
+            bins[b] = slots;
+            open_q = open_q && b < 255u && groups + c <= n / 128u;
+            open_h = open_h && b < 255u && groups + c <= n / 32u;
+            open = open && groups < n / 8u && groups + c <= n / 4u;
+            if (open_q) { q = b + 1u; slots += 4u * c; groups += c; }
+            else if (open_h) { h = b + 1u; slots += 2u * c; groups += c; }
+            else if (open) { thr = b + 1u; slots += c; groups += c; }
+            else open = false;
+        }
+        h = h < q ? q : h;
+        thr = thr < h ? h : thr;
+        s_q = q; s_h = h; s_thr = thr; s_front = slots;
+    }
+    __syncthreads();
+    const uint32_t q = s_q, h = s_h, thr = s_thr, front = s_front;
+    for (uint32_t g = t; g < n; g += 1024u) {
+        const uint32_t key = key_of(g);
+        if (key < q) {
+            const uint32_t at = atomicAdd(&bins[key], 4u);
+            for (uint32_t p = 0; p < 4u; ++p) order[at + p] = g | (2u << 28) | (p << 30);
+        } else if (key < h) {
+            const uint32_t at = atomicAdd(&bins[key], 2u);
+            for (uint32_t p = 0; p < 2u; ++p) order[at + p] = g | (1u << 28) | (p << 30);
+        } else if (key < thr) {
+            order[atomicAdd(&bins[key], 1u)] = g;
+        }
+    }
+    // the rest, stable: wave v of the 16 owns groups [v * per, v * per + per), 64 at a time (coalesced), ranks by ballot
+    const uint32_t lane = t & 63u, wv = t >> 6;
+    const uint32_t per = ((n + 15u) / 16u + 63u) & ~63u, g0 = min(n, wv * per), g1 = min(n, g0 + per);
+    uint32_t mine = 0;
+    for (uint32_t g = g0; g < g1; g += 64u)
+        mine += (uint32_t)__popcll(__ballot(g + lane < g1 && key_of(g + lane) >= thr));
+    if (lane == 0) scan[wv] = mine;
+    __syncthreads();
+    if (t == 0) {
+        uint32_t run = front;
+        for (uint32_t k = 0; k < 16u; ++k) { const uint32_t c = scan[k]; scan[k] = run; run += c; }
+        scan[16] = run;
+    }
+    __syncthreads();
+    uint32_t at = scan[wv];
+    for (uint32_t g = g0; g < g1; g += 64u) {
+        const bool sel = g + lane < g1 && key_of(g + lane) >= thr;
+        const unsigned long long m = __ballot(sel);
+        if (sel) order[at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = g + lane;
+        at += (uint32_t)__popcll(m);
+    }
+    const uint32_t used = scan[16];
+    for (uint32_t k = used + t; k < RT_ORDER_SLOTS(n); k += 1024u) order[k] = RT_ORDER_NONE;
+    __syncthreads();      // (every thread has read what it needs of the costs)
+    for (uint32_t k = t; k < 4u * n; k += 1024u) cost[k] = 0u;
 }
 
 // ---- sorted light loops: the hits of a bounce level ordered by where they lie -------------------------------------
@@ -2513,6 +2637,9 @@ void launch_shade(int form, bool count, const DScene& S, const LevelArgs& A, uin
     dim3 g(grid), b(RT_BLOCK);
     if (S.generic_pow) { if (count) launch_shade_t<true, true>(form, S, A, g, b, st); else launch_shade_t<false, true>(form, S, A, g, b, st); }
     else { if (count) launch_shade_t<true, false>(form, S, A, g, b, st); else launch_shade_t<false, false>(form, S, A, g, b, st); }
+}
+void launch_order_groups(uint32_t* cost_e, uint32_t* cost_s, uint32_t* order_e, uint32_t* order_s, uint8_t* key_e, uint8_t* key_s, uint32_t n, hipStream_t st) {
+    hipLaunchKernelGGL(k_order_groups, dim3(2), dim3(1024), 0, st, cost_e, cost_s, order_e, order_s, key_e, key_s, n);
 }
 size_t sort_hits_temp_bytes(uint32_t n_slots) {
     size_t bytes = 0;

@@ -127,6 +127,9 @@ struct LevelArgs {
     uint32_t debug;              // timing experiments only (RT_DEBUG_SKIP)
     uint32_t chunk_log2;         // level-0 shard chunks (RT_SHARD_CHUNK_LOG2; RT_CHUNK_LOG2 in the environment for experiments)
     uint4* wave_log;             // diagnostics (COUNT builds, RT_WAVE_LOG): per workgroup {start, end, traversal ticks, batches}
+    const uint32_t* order0;      // level-0 per-lane launches of a small one-pass frame: wave w takes group order0[w] - the groups in
+                                 // descending order of what they cost in the previous frame (k_order_groups); null: group w
+    uint32_t* cost0;             // ... and every wave leaves here how long its group took (10-ns ticks), for the next frame's order
     const uint32_t* perm;        // k_shade_wide as packets over levels >= 1: the hits of the range sorted by position (launch_sort_hits),
     uint32_t perm_n;             // perm_n slots (a multiple of 64; 0xFFFFFFFF = no entry); null: pool order
     PixelMap pm;
@@ -162,6 +165,19 @@ struct UntileArgs {
 // Device address of `scratch` on `device` (which must be the current device): hipGetSymbolAddress once per device,
 // remembered. Returns hipSuccess or the error.
 hipError_t noalloc_scratch(int device, void** ptr);
+
+// Expensive groups first, the most expensive in parts (level-0 launches of a one-pass frame of at most RT_ORDER_MAX_GROUPS
+// 64-sample groups; k_order_groups). An order entry = group | parts_log2 << 28 | part << 30: the wave takes lanes
+// [part * 64 >> parts_log2, (part + 1) * 64 >> parts_log2) of the group (a whole group, a half or a quarter: 8x8, 8x4 or 4x4
+// pixels); 0xFFFFFFFF: nothing. A launch with an order has RT_ORDER_SLOTS(n) waves. Costs: 4 words per group (one per
+// quarter; a wave adds its life in 10-ns ticks to the word of its first quarter), cleared by k_order_groups.
+#define RT_ORDER_MAX_GROUPS (1u << 16)
+#define RT_ORDER_SLOTS(n) ((n) + ((n) >> 4))
+#define RT_ORDER_NONE 0xFFFFFFFFu
+// two workgroups, one per cost array (closest hits, light loops): cost_* 4 n words, order_* RT_ORDER_SLOTS(n) words, key_* n
+// bytes of scratch
+void launch_order_groups(uint32_t* cost_e, uint32_t* cost_s, uint32_t* order_e, uint32_t* order_s, uint8_t* key_e, uint8_t* key_s,
+                         uint32_t n, hipStream_t st);
 
 // Kernel forms: one ray per lane (suspends at meshes), one ray per quad from the start, one per quad resuming the queue.
 // RT_FORM_QUAD_PARKED (shade only): one hit per quad from the start, for the rays of the level's extend queue.

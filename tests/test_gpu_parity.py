@@ -386,6 +386,46 @@ def test_traversal_forms_agree(spp_grid):
     assert np.array_equal(default_img, base[0]) and st.trace_calls == base[1]
 
 
+def test_expensive_groups_first_agree():
+    """Option "order0" (on by default): the level-0 launches of a small one-pass frame hand out their 64-sample groups in
+    descending order of what they cost in the scene's previous frame, the most expensive as two halves or four quarters
+    (k_order_groups). Only which wave works on which entries changes: frame after frame - each ordered by its predecessor's
+    costs, with and without a wait in between, single frames and a batch, after a change of frame size - equals the frames of
+    a scene that never orders, and so do the ray counts."""
+    import torch
+    fs = wl.scene_bunny(10, third="glass2")
+    p = Params(max_depth=6)
+    plain = DeviceScene(fs)
+    plain.set_option("order0", 0)
+    dev = DeviceScene(fs)
+    stream = torch.cuda.Stream()
+    for (w, h) in ((512, 384), (640, 480), (512, 384)):          # 3072 / 4800 groups: the arrays grow, then an order of another size is stale
+        cam = reference_camera(w, h)
+        want, st_w = plain.render(cam, p)
+        out = torch.zeros((h, w, 3), dtype=torch.uint8, device="cuda")
+        for k in range(7):
+            with torch.cuda.stream(stream):
+                out.zero_()
+                dev.render_device(cam, p, out.data_ptr(), stream=stream.cuda_stream)
+                if k % 2:
+                    torch.cuda.synchronize()      # with it the next frame finds the order finished, without it maybe not
+                stream.synchronize()
+            assert np.array_equal(out.cpu().numpy(), want), (w, h, k)
+        img, st = dev.render(cam, p)                              # (the timed path: every launch on one stream)
+        assert np.array_equal(img, want)
+        assert (st.trace_calls, st.shadow_rays, list(st.level_rays)) == (st_w.trace_calls, st_w.shadow_rays, list(st_w.level_rays))
+    cams = wl.orbit_cameras(512, 384, 4)
+    ref = torch.zeros((4, 384, 512, 3), dtype=torch.uint8, device="cuda")
+    out = torch.zeros_like(ref)
+    with torch.cuda.stream(stream):
+        plain.render_batch_device(cams, p, ref.data_ptr(), 384 * 512 * 3, stream=stream.cuda_stream)
+        for k in range(4):
+            out.zero_()
+            dev.render_batch_device(cams, p, out.data_ptr(), 384 * 512 * 3, stream=stream.cuda_stream)
+            torch.cuda.synchronize()
+            assert bool(torch.equal(out, ref)), k
+
+
 @pytest.mark.parametrize("bits", [2, 8, 10])
 def test_sorted_light_loops_agree(bits):
     """Option "sort_shade" (off by default: measured slower): the hits of a bounce level sorted by the cell of their hit point
