@@ -1999,11 +1999,20 @@ __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WPE
 //     lies (a frame whose groups all cost the same is left alone);
 //   * with the long waves first a launch is as long as its longest wave (89 us of closest hits, 139 us of light loops,
 //     on a chip that has been empty for half of that), so the most expensive groups are worked on in PARTS by several
-//     waves: the top 1/128 as four quarters (4x4 pixels each), up to the top 1/32 as two halves. A part's packet visits
+//     waves: the top 1/256 as four quarters (4x4 pixels each), up to the top 1/128 as two halves. A part's packet visits
 //     what its own rays visit: a wave of 16 rays executes fewer steps than the wave of 64 did.
 // Only WHICH wave works on WHICH entries, and when, changes - pool positions, shards and results do not - and a stale or
 // missing order (first frame, camera cut) costs time, never pixels. The costs are cleared here for the next frame (a wave
 // writes the word of its first quarter; a group's cost is the sum of its four words).
+// (measured, level-0 launches of one 1080p frame, closest hits / light loops in us: quarters for the top 1/32 and halves up to
+// 1/8: 74 / 155; 1/64, 1/16: 68 / 133; 1/128, 1/32: 67 / 122; 1/256, 1/64: 67 / 119; 1/256, 1/128: 67 / 117; 1/512, 1/128: 69 / 115;
+// 1/1024, 1/256: 70 / 114 - a part's waves cost more in all than the whole did, so only the few that set the launch's length)
+#ifndef RT_ORDER_Q_DIV
+#define RT_ORDER_Q_DIV 256u
+#endif
+#ifndef RT_ORDER_H_DIV
+#define RT_ORDER_H_DIV 128u
+#endif
 __global__ __launch_bounds__(1024) void k_order_groups(uint32_t* __restrict__ cost_e, uint32_t* __restrict__ cost_s,
                                                        uint32_t* __restrict__ order_e, uint32_t* __restrict__ order_s,
                                                        uint8_t* __restrict__ key_e, uint8_t* __restrict__ key_s, uint32_t n) {
@@ -2035,8 +2044,8 @@ __global__ __launch_bounds__(1024) void k_order_groups(uint32_t* __restrict__ co
         for (uint32_t b = 0; b < 256u; ++b) {
             const uint32_t c = bins[b];
             bins[b] = slots;
-            open_q = open_q && b < 255u && groups + c <= n / 128u;
-            open_h = open_h && b < 255u && groups + c <= n / 32u;
+            open_q = open_q && b < 255u && groups + c <= n / RT_ORDER_Q_DIV;
+            open_h = open_h && b < 255u && groups + c <= n / RT_ORDER_H_DIV;
             open = open && groups < n / 8u && groups + c <= n / 4u;
             if (open_q) { q = b + 1u; slots += 4u * c; groups += c; }
             else if (open_h) { h = b + 1u; slots += 2u * c; groups += c; }

@@ -172,7 +172,10 @@ hipError_t noalloc_scratch(int device, void** ptr);
 // pixels); 0xFFFFFFFF: nothing. A launch with an order has RT_ORDER_SLOTS(n) waves. Costs: 4 words per group (one per
 // quarter; a wave adds its life in 10-ns ticks to the word of its first quarter), cleared by k_order_groups.
 #define RT_ORDER_MAX_GROUPS (1u << 16)
-#define RT_ORDER_SLOTS(n) ((n) + ((n) >> 4))
+#ifndef RT_ORDER_SLOTS_SHIFT
+#define RT_ORDER_SLOTS_SHIFT 4
+#endif
+#define RT_ORDER_SLOTS(n) ((n) + ((n) >> RT_ORDER_SLOTS_SHIFT))
 #define RT_ORDER_NONE 0xFFFFFFFFu
 // two workgroups, one per cost array (closest hits, light loops): cost_* 4 n words, order_* RT_ORDER_SLOTS(n) words, key_* n
 // bytes of scratch
