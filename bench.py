@@ -573,8 +573,10 @@ def extras(args, out, dev, slots, fs, cam, cams, params, st, rays_per_frame, cam
     # (a scene whose level 0 is traversed as packets has no quad launches at level 0: the per-lane kernels'
     # PACKET instantiations do the whole level)
     pk = "true" if (fs.num_faces and not n0[2]) else "false"
-    rocprof_names = (f"k_extend_wide<0, false, {pk}>", f"k_shade_wide<false, false, {pk}>", "k_extend_quad<0, false, false>",
-                     "k_shade_quad<1, false, false>", "k_shade_quad<2, false, false>")
+    # (the per-lane kernels' last template argument: the instantiation that hands out level 0's groups in the order of
+    # the previous frame's costs - which of the two a workload's level 0 runs is read from the counters file below)
+    rocprof_names = [f"k_extend_wide<0, false, {pk}, false>", f"k_shade_wide<false, false, {pk}, false>", "k_extend_quad<0, false, false>",
+                     "k_shade_quad<1, false, false>", "k_shade_quad<2, false, false>"]
     dk = max(range(2), key=lambda k: ms0[k] / max(n0[k], 1))      # level 0 = the two per-lane launches
     avg_ms = ms0[dk] / n0[dk]
     launches = n0[dk] / reps                                       # per depth-0 frame = its passes
@@ -601,7 +603,11 @@ def extras(args, out, dev, slots, fs, cam, cams, params, st, rays_per_frame, cam
     if ctr_files:
         cj = json.load(open(ctr_files[-1]))
         stale = cj.get("kernels_hash") != kernels_hash()
-        ctr = cj.get("depth0", {}).get(rocprof_names[dk])
+        d0 = cj.get("depth0", {})
+        ordered_name = rocprof_names[dk].replace(", false>", ", true>")
+        if dk < 2 and d0.get(ordered_name, {}).get("launches", 0) > d0.get(rocprof_names[dk], {}).get("launches", 0):
+            rocprof_names[dk] = ordered_name
+        ctr = d0.get(rocprof_names[dk])
         if ctr:      # a frame of several passes launches the kernel once per pass: counters per LAUNCH
             nl = max(ctr.get("launches", 1.0), 1.0)
             ctr = {k: v / nl for k, v in ctr.items()}

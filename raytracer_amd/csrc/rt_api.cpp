@@ -875,6 +875,7 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
         // of what they cost in the scene's previous frame of the same size. Not for the static pool (allocates) or a graph.
         const uint32_t n_grp0 = (A.n0 + 63u) / 64u;
         bool order_on = s->knobs.order0 && px0 == 0 && done == 0 && npx <= pass_px && n_grp0 >= 2048u && n_grp0 <= RT_ORDER_MAX_GROUPS &&
+                        s->d.packet && !s->d.generic_pow && !s->count_work &&      // (the kernels that log and follow an order: k_extend_wide / k_shade_wide <.., ORDERED>)
                         s->knobs.grid0 == 0 && !J.noalloc && !s->knobs.use_graph && ensure_order_buf(s, n_grp0, sa);
         const uint32_t* order_e = nullptr;
         const uint32_t* order_s = nullptr;

@@ -1578,7 +1578,10 @@ __device__ __forceinline__ LevelArgs reload_level_args() {
 }
 
 // k_extend_wide: one ray per lane. Rays that never reach a mesh are finished here; the others are queued.
-template <int SRC, bool COUNT, int PACKET>
+// ORDERED (camera rays as packets only): the launch logs what each group cost (LevelArgs::cost0) and, when the previous frame
+// left an order (LevelArgs::order0), hands the groups out in it - a kernel of its own, so that every other launch keeps
+// the registers of the plain loop (as one kernel: 8 to 20 more spilled SGPRs in each per-lane kernel, batched frames 2-5 % slower).
+template <int SRC, bool COUNT, int PACKET, bool ORDERED = false>
 __device__ __forceinline__ void extend_wide_body(const DScene& S, const LevelArgs& A_, uint32_t* lds) {
     const LevelArgs& A = A_;
     const bool level0 = SRC != 1;
@@ -1592,19 +1595,20 @@ __device__ __forceinline__ void extend_wide_body(const DScene& S, const LevelArg
     // a workgroup is 1..4 independent waves (RT_WIDE_BLOCK: the dispatcher starts workgroups at a limited rate, and these
     // waves are short-lived), wave w of workgroup b takes groups b * waves + w, ...
     const uint32_t nwv = blockDim.x >> 6;
-    const bool ordered = level0 && A.order0;      // (wave-uniform)
+    const bool ordered = ORDERED && level0 && A.order0;      // (wave-uniform)
+    const bool costs = ORDERED && level0 && A.cost0;
     const uint32_t n_w = ordered ? RT_ORDER_SLOTS(G.total) : G.total;
     for (uint32_t w = blockIdx.x * nwv + (threadIdx.x >> 6); w < n_w; w += gridDim.x * nwv) {
         // (level 0 of a small frame: the groups in descending order of last frame's cost, the dearest in parts: k_order_groups)
         const uint32_t code = ordered ? ((const RT_CONSTANT uint32_t*)(const void*)A.order0)[w] : w;
-        if (code == RT_ORDER_NONE) continue;                                                   // wave-uniform
+        if (ORDERED && code == RT_ORDER_NONE) continue;                                        // wave-uniform
         const uint32_t grp = ordered ? (code & 0x0FFFFFFFu) : code, parts_log2 = ordered ? ((code >> 28) & 3u) : 0u, part = ordered ? (code >> 30) : 0u;
-        if (grp >= G.total) continue;                                                          // (an order is only ever a hint: never out of range)
-        const unsigned long long t_grp = (level0 && A.cost0) ? wall_clock64() : 0ull;
+        if (ORDERED && grp >= G.total) continue;                                               // (an order is only ever a hint: never out of range)
+        const unsigned long long t_grp = costs ? wall_clock64() : 0ull;
         uint32_t shard, pos, lim;
         locate(G, grp, shard, pos, lim);
         const uint32_t i = pos + (threadIdx.x & 63u);
-        const bool active = i < lim && ((threadIdx.x & 63u) >> (6u - parts_log2)) == part;
+        const bool active = i < lim && (!ORDERED || ((threadIdx.x & 63u) >> (6u - parts_log2)) == part);
         Ray ray;
         ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 0);
         bool valid;
@@ -1630,7 +1634,7 @@ __device__ __forceinline__ void extend_wide_body(const DScene& S, const LevelArg
         }
         extend_finish(S, A, i, active && !parked, valid && !parked, true, ray, h, lane_read(next_base_l, shard),
                       A.n0 + (shard + 1u) * A.sub_cap, sc->level + (A.level + 1), 0u, A.level);
-        if (level0 && A.cost0 && lane_id() == 0)      // (the word of the wave's first quarter; a group that was not split: word 0)
+        if (ORDERED && level0 && A.cost0 && lane_id() == 0)      // (the word of the wave's first quarter; a group that was not split: word 0)
             A.cost0[4u * grp + (part << (2u - parts_log2))] = (uint32_t)min(wall_clock64() - t_grp, 0xFFFFull);
     }
     if (COUNT) {
@@ -1644,9 +1648,9 @@ __device__ __forceinline__ void extend_wide_body(const DScene& S, const LevelArg
         if (wid < 4u * 8192u) A.wave_log[wid] = make_uint4((uint32_t)wk.t_start, (uint32_t)wall_clock64(), 0u, 0u);
     }
 }
-template <int SRC, bool COUNT, bool PACKET>
+template <int SRC, bool COUNT, bool PACKET, bool ORDERED = false>
 __global__ __launch_bounds__(RT_WIDE_BLOCK_MAX) __attribute__((amdgpu_waves_per_eu(PACKET ? RT_WPE_PK : RT_WPE_EW))) void k_extend_wide(DScene S, LevelArgs A) {
-    extend_wide_body<SRC, COUNT, PACKET ? 1 : 0>(S, A, nullptr);
+    extend_wide_body<SRC, COUNT, PACKET ? 1 : 0, ORDERED>(S, A, nullptr);
 }
 // the rays of a level >= 1, one per lane, meshes by quad service
 // (SRC 2: rt_trace_form's caller-supplied rays, for the parity tests)
@@ -1810,10 +1814,11 @@ __device__ __forceinline__ void flush_shadow(const LevelArgs& A, uint32_t n_shad
 
 // k_shade_wide: light loop, one hit per lane, for the hits of levels A.level..A.level_hi. Hits whose shadow rays never
 // reach a mesh are finished here; the others are queued (queue of A.level) at the point they stopped.
-template <bool COUNT, bool GPOW, int PACKET>
+// ORDERED: see extend_wide_body (level 0 only).
+template <bool COUNT, bool GPOW, int PACKET, bool ORDERED = false>
 __device__ __forceinline__ void shade_wide_body(const DScene& S, const LevelArgs& A_, uint32_t* lds) {
     const LevelArgs& A = A_;
-    const bool level0 = A.level == 0;                 // then level_hi == 0: level 0 is not part of a range
+    const bool level0 = ORDERED || A.level == 0;      // then level_hi == 0: level 0 is not part of a range
     const ShardView v = shard_view(A, A.level, A.level_hi);
     const Groups G = level0 ? make_groups_dense<false>(A.n0, A.chunk_log2) : make_groups<false>(v.start, v.cnt);
     Work wk = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1828,16 +1833,16 @@ __device__ __forceinline__ void shade_wide_body(const DScene& S, const LevelArgs
     // are walked in pool order as ever.
     const uint32_t n_perm = (PACKET == 1 && !level0 && A.perm) ? (A.perm_n >> 6) : 0u;
     const uint32_t n_groups = G.total > n_perm ? G.total : n_perm;
-    const bool ordered = level0 && A.order0;      // (wave-uniform)
+    const bool ordered = ORDERED && A.order0;     // (wave-uniform)
     const uint32_t n_w = ordered ? RT_ORDER_SLOTS(n_groups) : n_groups;
     for (uint32_t w = blockIdx.x * nwv + (threadIdx.x >> 6); w < n_w; w += gridDim.x * nwv) {
         // (level 0 of a small frame: the groups in descending order of last frame's cost, the dearest in parts: k_order_groups)
         const uint32_t code = ordered ? ((const RT_CONSTANT uint32_t*)(const void*)A.order0)[w] : w;
-        if (code == RT_ORDER_NONE) continue;                                                   // wave-uniform
+        if (ORDERED && code == RT_ORDER_NONE) continue;                                        // wave-uniform
         const uint32_t grp = ordered ? (code & 0x0FFFFFFFu) : code, parts_log2 = ordered ? ((code >> 28) & 3u) : 0u, part = ordered ? (code >> 30) : 0u;
-        if (ordered && grp >= n_groups) continue;                                              // (an order is only ever a hint: never out of range)
+        if (ORDERED && grp >= n_groups) continue;                                              // (an order is only ever a hint: never out of range)
         const uint32_t cost_word = 4u * grp + (part << (2u - parts_log2));
-        const unsigned long long t_grp = (level0 && A.cost0) ? wall_clock64() : 0ull;
+        const unsigned long long t_grp = (ORDERED && A.cost0) ? wall_clock64() : 0ull;
         uint32_t shard = 0, pos = 0, lim = 0;
         uint32_t i;
         bool have;
@@ -1848,7 +1853,7 @@ __device__ __forceinline__ void shade_wide_body(const DScene& S, const LevelArgs
         } else {
             locate(G, grp, shard, pos, lim);
             i = pos + (threadIdx.x & 63u);
-            have = i < lim && ((threadIdx.x & 63u) >> (6u - parts_log2)) == part;
+            have = i < lim && (!ORDERED || ((threadIdx.x & 63u) >> (6u - parts_log2)) == part);
         }
         uint4 b = make_uint4(0, 0, 0, 0);
         float4 hn = make_float4(0, 0, 0, 0), hp = make_float4(0, 0, 0, 0);
@@ -1858,7 +1863,7 @@ __device__ __forceinline__ void shade_wide_body(const DScene& S, const LevelArgs
             if (have) b = pool_ld(Af.node_b + i);
             hit = (b.w & (NODE_HIT | NODE_PARKED)) == NODE_HIT;
             if (!__any(hit)) {                                                               // wave-uniform
-                if (level0 && Af.cost0 && lane_id() == 0) Af.cost0[cost_word] = 0u;
+                if (ORDERED && Af.cost0 && lane_id() == 0) Af.cost0[cost_word] = 0u;
                 continue;
             }
             if (hit) { hn = pool_ld(Af.hit_n + i); hp = pool_ld(Af.hit_p + i); }
@@ -1867,7 +1872,7 @@ __device__ __forceinline__ void shade_wide_body(const DScene& S, const LevelArgs
         shade_ray<false, COUNT, GPOW, PACKET>(S, A, i, b, hit, true, f4xyz(hn), f4xyz(hp), hp.w, hn.w, 0, 0, false, mk(0, 0, 0), lds, wk,
                                 n_shadow, parked, level0 || n_perm != 0u);      // the hits of camera rays / sorted hits: neighbours
         const LevelArgs A = (RT_RELOAD_FOR(PACKET)) ? reload_level_args() : A_;
-        if (level0 && A.cost0 && lane_id() == 0) A.cost0[cost_word] = (uint32_t)min(wall_clock64() - t_grp, 0xFFFFull);
+        if (ORDERED && A.cost0 && lane_id() == 0) A.cost0[cost_word] = (uint32_t)min(wall_clock64() - t_grp, 0xFFFFull);
         if (level0) {       // mark; hit_n.w (tmpdist at the start of the light loop) is not needed again: keep the resume point there
             if (parked >= 0) { A.node_b[i].w = b.w | NODE_SPARKED; A.hit_n[i].w = __uint_as_float((uint32_t)parked); }
         } else {
@@ -1887,10 +1892,10 @@ __device__ __forceinline__ void shade_wide_body(const DScene& S, const LevelArgs
         if (wid < 4u * 8192u) A.wave_log[wid] = make_uint4((uint32_t)wk.t_start, (uint32_t)wall_clock64(), 0u, 0u);
     }
 }
-template <bool COUNT, bool GPOW, bool PACKET>
+template <bool COUNT, bool GPOW, bool PACKET, bool ORDERED = false>
 __global__ __launch_bounds__(RT_WIDE_BLOCK_MAX) __attribute__((amdgpu_waves_per_eu(PACKET ? RT_WPE_PKS : RT_WPE_SW))) void k_shade_wide(DScene S, LevelArgs A) {
     extern __shared__ uint32_t pk_lds[];      // packet_traverse: the rays of a compacted leaf, RT_PK_LDS_WORDS per wave (dynamic: sized for the launch's waves)
-    shade_wide_body<COUNT, GPOW, PACKET ? 1 : 0>(S, A, PACKET ? pk_lds + (threadIdx.x >> 6) * RT_PK_LDS_WORDS : nullptr);
+    shade_wide_body<COUNT, GPOW, PACKET ? 1 : 0, ORDERED>(S, A, PACKET ? pk_lds + (threadIdx.x >> 6) * RT_PK_LDS_WORDS : nullptr);
 }
 // the hits of levels >= 1, one per lane, shadow rays through meshes by quad service
 template <bool COUNT, bool GPOW>
@@ -2617,6 +2622,7 @@ static void launch_extend_src(int form, bool count, const DScene& S, const Level
         g = dim3((g.x + wide_waves() - 1u) / wide_waves());
         if ((SRC == 0 && S.packet) || (SRC == 1 && S.packet >= 2) || (SRC == 2 && S.user_packet)) {     // primary rays: coherent, traversed as packets in the per-lane kernel itself (2: deeper levels too; user_packet: rt_trace_form)
             if (count) hipLaunchKernelGGL((k_extend_wide<SRC, true, true>), g, b, 0, st, S, A);
+            else if (SRC == 0 && A.cost0) hipLaunchKernelGGL((k_extend_wide<0, false, true, true>), g, b, 0, st, S, A);      // expensive groups first
             else hipLaunchKernelGGL((k_extend_wide<SRC, false, true>), g, b, 0, st, S, A);
         } else {
             if (count) hipLaunchKernelGGL((k_extend_wide<SRC, true, false>), g, b, 0, st, S, A);
@@ -2646,7 +2652,11 @@ static void launch_shade_t(int form, const DScene& S, const LevelArgs& A, dim3 g
         b = dim3(64u * wide_waves());
         g = dim3((g.x + wide_waves() - 1u) / wide_waves());
         // the hits of primary rays: their shadow rays are coherent too (rt_trace's caller-supplied rays need not be)
-        if (S.packet && (A.level == 0 || S.packet >= 2) && (!A.user_rays || S.user_packet)) hipLaunchKernelGGL((k_shade_wide<COUNT, GPOW, true>), g, b, RT_LEAF_COMPACT ? wide_waves() * RT_PK_LDS_WORDS * 4u : 0u, st, S, A);
+        const uint32_t pk_lds = RT_LEAF_COMPACT ? wide_waves() * RT_PK_LDS_WORDS * 4u : 0u;
+        if (S.packet && (A.level == 0 || S.packet >= 2) && (!A.user_rays || S.user_packet)) {
+            if (!COUNT && !GPOW && A.level == 0 && A.cost0) hipLaunchKernelGGL((k_shade_wide<false, false, true, true>), g, b, pk_lds, st, S, A);      // expensive groups first
+            else hipLaunchKernelGGL((k_shade_wide<COUNT, GPOW, true>), g, b, pk_lds, st, S, A);
+        }
         else hipLaunchKernelGGL((k_shade_wide<COUNT, GPOW, false>), g, b, 0, st, S, A);
     }
     else if (form == RT_FORM_WIDE_SERVE) hipLaunchKernelGGL((k_shade_serve<COUNT, GPOW>), g, b, 0, st, S, A);
