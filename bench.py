@@ -604,9 +604,10 @@ def extras(args, out, dev, slots, fs, cam, cams, params, st, rays_per_frame, cam
         cj = json.load(open(ctr_files[-1]))
         stale = cj.get("kernels_hash") != kernels_hash()
         d0 = cj.get("depth0", {})
-        ordered_name = rocprof_names[dk].replace(", false>", ", true>")
-        if dk < 2 and d0.get(ordered_name, {}).get("launches", 0) > d0.get(rocprof_names[dk], {}).get("launches", 0):
-            rocprof_names[dk] = ordered_name
+        for k in range(2):
+            ordered_name = rocprof_names[k].replace(", false>", ", true>")
+            if d0.get(ordered_name, {}).get("launches", 0) > d0.get(rocprof_names[k], {}).get("launches", 0):
+                rocprof_names[k] = ordered_name
         ctr = d0.get(rocprof_names[dk])
         if ctr:      # a frame of several passes launches the kernel once per pass: counters per LAUNCH
             nl = max(ctr.get("launches", 1.0), 1.0)
