@@ -375,6 +375,7 @@ def test_traversal_forms_agree(spp_grid):
         dev.set_option("large_threshold", int(thr))      # rays from which a bounce level is "large"
         dev.set_option("serve", int(serve))              # bounce levels one ray per lane with quad service / one ray per quad
         dev.set_option("split_small", int(split))        # small levels shaded per lane + resuming quads / one quad launch per run
+        dev.set_option("tiny_run", 1024)                 # (runs of more hits than this take the split path: the default, 8192, would leave few at this size)
         dev.render(cam, p)                               # (the second frame of a scene knows its level sizes)
         img, st = dev.render(cam, p)
         frames[(packet, thr, serve, split, tail)] = (img, st.trace_calls, st.shadow_rays, list(st.level_rays))
