@@ -573,10 +573,12 @@ def extras(args, out, dev, slots, fs, cam, cams, params, st, rays_per_frame, cam
     # (a scene whose level 0 is traversed as packets has no quad launches at level 0: the per-lane kernels'
     # PACKET instantiations do the whole level)
     pk = "true" if (fs.num_faces and not n0[2]) else "false"
-    # (the per-lane kernels' last template argument: the instantiation that hands out level 0's groups in the order of
-    # the previous frame's costs - which of the two a workload's level 0 runs is read from the counters file below)
-    rocprof_names = [f"k_extend_wide<0, false, {pk}, false>", f"k_shade_wide<false, false, {pk}, false>", "k_extend_quad<0, false, false>",
-                     "k_shade_quad<1, false, false>", "k_shade_quad<2, false, false>"]
+    # (the per-lane kernels' last template argument: k_extend_wide - whether it hands out level 0's groups in the order of the
+    # previous frame's costs; k_shade_wide - 0 any level, 1 level 0, 2 level 0 in that order. Which instantiation a
+    # workload's level 0 runs is read from the counters file below)
+    rocprof_names = [f"k_extend_wide<0, false, {pk}, false>", f"k_shade_wide<false, false, {pk}, {1 if pk == 'true' else 0}>",
+                     "k_extend_quad<0, false, false>", "k_shade_quad<1, false, false>", "k_shade_quad<2, false, false>"]
+    rocprof_alt = [[f"k_extend_wide<0, false, {pk}, true>"], [f"k_shade_wide<false, false, {pk}, {m}>" for m in (0, 1, 2)]]
     dk = max(range(2), key=lambda k: ms0[k] / max(n0[k], 1))      # level 0 = the two per-lane launches
     avg_ms = ms0[dk] / n0[dk]
     launches = n0[dk] / reps                                       # per depth-0 frame = its passes
@@ -605,9 +607,9 @@ def extras(args, out, dev, slots, fs, cam, cams, params, st, rays_per_frame, cam
         stale = cj.get("kernels_hash") != kernels_hash()
         d0 = cj.get("depth0", {})
         for k in range(2):
-            ordered_name = rocprof_names[k].replace(", false>", ", true>")
-            if d0.get(ordered_name, {}).get("launches", 0) > d0.get(rocprof_names[k], {}).get("launches", 0):
-                rocprof_names[k] = ordered_name
+            for alt in rocprof_alt[k]:
+                if d0.get(alt, {}).get("launches", 0) > d0.get(rocprof_names[k], {}).get("launches", 0):
+                    rocprof_names[k] = alt
         ctr = d0.get(rocprof_names[dk])
         if ctr:      # a frame of several passes launches the kernel once per pass: counters per LAUNCH
             nl = max(ctr.get("launches", 1.0), 1.0)

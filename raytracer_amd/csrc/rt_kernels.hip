@@ -1814,11 +1814,14 @@ __device__ __forceinline__ void flush_shadow(const LevelArgs& A, uint32_t n_shad
 
 // k_shade_wide: light loop, one hit per lane, for the hits of levels A.level..A.level_hi. Hits whose shadow rays never
 // reach a mesh are finished here; the others are queued (queue of A.level) at the point they stopped.
-// ORDERED: see extend_wide_body (level 0 only).
-template <bool COUNT, bool GPOW, int PACKET, bool ORDERED = false>
+// LEVEL0 (packets): 0 any level(s); 1 the launch is over level 0 and the kernel knows it (no range of levels, no queue, no
+// permutation: 6 SGPR spills and 6 VGPRs less - bunny_1080p in batches 0.2111 -> 0.2094 ms, shadows-only bunny 0.135 -> 0.133,
+// field at 1080p 3.94 -> 3.90, 4K glass scene 27.3 -> 26.6); 2 level 0, expensive groups first (ORDERED: see extend_wide_body).
+template <bool COUNT, bool GPOW, int PACKET, int LEVEL0 = 0>
 __device__ __forceinline__ void shade_wide_body(const DScene& S, const LevelArgs& A_, uint32_t* lds) {
     const LevelArgs& A = A_;
-    const bool level0 = ORDERED || A.level == 0;      // then level_hi == 0: level 0 is not part of a range
+    constexpr bool ORDERED = LEVEL0 == 2;
+    const bool level0 = LEVEL0 != 0 || A.level == 0;      // then level_hi == 0: level 0 is not part of a range
     const ShardView v = shard_view(A, A.level, A.level_hi);
     const Groups G = level0 ? make_groups_dense<false>(A.n0, A.chunk_log2) : make_groups<false>(v.start, v.cnt);
     Work wk = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1892,10 +1895,10 @@ __device__ __forceinline__ void shade_wide_body(const DScene& S, const LevelArgs
         if (wid < 4u * 8192u) A.wave_log[wid] = make_uint4((uint32_t)wk.t_start, (uint32_t)wall_clock64(), 0u, 0u);
     }
 }
-template <bool COUNT, bool GPOW, bool PACKET, bool ORDERED = false>
+template <bool COUNT, bool GPOW, bool PACKET, int LEVEL0 = 0>
 __global__ __launch_bounds__(RT_WIDE_BLOCK_MAX) __attribute__((amdgpu_waves_per_eu(PACKET ? RT_WPE_PKS : RT_WPE_SW))) void k_shade_wide(DScene S, LevelArgs A) {
     extern __shared__ uint32_t pk_lds[];      // packet_traverse: the rays of a compacted leaf, RT_PK_LDS_WORDS per wave (dynamic: sized for the launch's waves)
-    shade_wide_body<COUNT, GPOW, PACKET ? 1 : 0, ORDERED>(S, A, PACKET ? pk_lds + (threadIdx.x >> 6) * RT_PK_LDS_WORDS : nullptr);
+    shade_wide_body<COUNT, GPOW, PACKET ? 1 : 0, LEVEL0>(S, A, PACKET ? pk_lds + (threadIdx.x >> 6) * RT_PK_LDS_WORDS : nullptr);
 }
 // the hits of levels >= 1, one per lane, shadow rays through meshes by quad service
 template <bool COUNT, bool GPOW>
@@ -2654,9 +2657,11 @@ static void launch_shade_t(int form, const DScene& S, const LevelArgs& A, dim3 g
         // the hits of primary rays: their shadow rays are coherent too (rt_trace's caller-supplied rays need not be)
         const uint32_t pk_lds = RT_LEAF_COMPACT ? wide_waves() * RT_PK_LDS_WORDS * 4u : 0u;
         if (S.packet && (A.level == 0 || S.packet >= 2) && (!A.user_rays || S.user_packet)) {
-            if (!COUNT && !GPOW && A.level == 0 && A.cost0) hipLaunchKernelGGL((k_shade_wide<false, false, true, true>), g, b, pk_lds, st, S, A);      // expensive groups first
+            if (!COUNT && !GPOW && A.level == 0 && A.level_hi == 0 && A.cost0) hipLaunchKernelGGL((k_shade_wide<false, false, true, 2>), g, b, pk_lds, st, S, A);      // expensive groups first
+            else if (!COUNT && !GPOW && A.level == 0 && A.level_hi == 0) hipLaunchKernelGGL((k_shade_wide<false, false, true, 1>), g, b, pk_lds, st, S, A);
             else hipLaunchKernelGGL((k_shade_wide<COUNT, GPOW, true>), g, b, pk_lds, st, S, A);
         }
+        else if (!COUNT && !GPOW && A.level == 0 && A.level_hi == 0 && !A.user_rays) hipLaunchKernelGGL((k_shade_wide<false, false, false, 1>), g, b, 0, st, S, A);
         else hipLaunchKernelGGL((k_shade_wide<COUNT, GPOW, false>), g, b, 0, st, S, A);
     }
     else if (form == RT_FORM_WIDE_SERVE) hipLaunchKernelGGL((k_shade_serve<COUNT, GPOW>), g, b, 0, st, S, A);
