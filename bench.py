@@ -579,12 +579,22 @@ def extras(args, out, dev, slots, fs, cam, cams, params, st, rays_per_frame, cam
     rocprof_names = [f"k_extend_wide<0, false, {pk}, false>", f"k_shade_wide<false, false, {pk}, {1 if pk == 'true' else 0}>",
                      "k_extend_quad<0, false, false>", "k_shade_quad<1, false, false>", "k_shade_quad<2, false, false>"]
     rocprof_alt = [[f"k_extend_wide<0, false, {pk}, true>"], [f"k_shade_wide<false, false, {pk}, {m}>" for m in (0, 1, 2)]]
+    # (a scene without meshes runs a level as ONE launch, k_trace_wide: closest hits and light loops; its work is both kinds')
+    fused0 = bool(n0[0] and not n0[1] and s0.shadow_rays)
+    if fused0:
+        rocprof_names[0] = "k_trace_wide<0, false>"
+        rocprof_alt[0] = ["k_trace_wide<0, true>"]
     dk = max(range(2), key=lambda k: ms0[k] / max(n0[k], 1))      # level 0 = the two per-lane launches
     avg_ms = ms0[dk] / n0[dk]
     launches = n0[dk] / reps                                       # per depth-0 frame = its passes
     rays_k = s0.trace_calls if dk == 0 else s0.shadow_rays
     hits = s0.shadow_rays // max(len(fs.lights), 1)
     b_frame, f_frame = algorithmic_work(per_ray[dk], rays_k, hits if dk == 1 else 0, len(fs.lights))
+    units = dict(per_ray[dk])
+    if fused0:
+        b2, f2 = algorithmic_work(per_ray[1], s0.shadow_rays, hits, len(fs.lights))
+        b_frame, f_frame, rays_k = b_frame + b2, f_frame + f2, s0.trace_calls + s0.shadow_rays
+        units = {k: per_ray[0][k] + per_ray[1][k] for k in per_ray[0]}
     b_alg, f_alg = b_frame / launches, f_frame / launches         # the census is of the whole frame: ONE launch is a pass of it
     clock_mhz = 100.0 * wp[dk].wave_cycles_sum / max(wp[dk].wave_ticks_sum, 1)
     if not 500.0 < clock_mhz < 3000.0:
@@ -628,7 +638,7 @@ def extras(args, out, dev, slots, fs, cam, cams, params, st, rays_per_frame, cam
                           "dense contraction); traffic = HBM bytes per launch from the PMC counters (2 x FETCH_SIZE + WRITE_SIZE)",
             "shader_clock_mhz": clock_mhz, "peak_at_2400_mhz": VALU_PEAK_TFLOPS, "frac_of_peak_at_2400_mhz": alg_tfl / VALU_PEAK_TFLOPS,
             "avg_launch_ms": avg_ms, "launches_per_frame_at_depth0": launches,
-            "units_per_launch": dict({k: v / launches for k, v in per_ray[dk].items()}, rays=rays_k / launches,
+            "units_per_launch": dict({k: v / launches for k, v in units.items()}, rays=rays_k / launches,
                                      note="per RAY: each ray traversed by itself (RT_SCENE_NO_PACKETS census of the same frame), "
                                           "divided by the frame's launches of this kernel (one per pass)"),
             "packet_steps_per_launch": {"wave_node_steps": wp[dk].wave_node_steps / launches, "wave_tri_steps": wp[dk].wave_tri_steps / launches,

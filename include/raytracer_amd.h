@@ -348,6 +348,7 @@ int rt_scene_set_pass_samples(rt_scene* scene, uint32_t samples);
  *   "large_max_level"  deepest level that may do so (-1: built-in)
  *   "serve"            bounce levels as per-lane kernels with quad service: 0 never | 1 always | -1 by pass size
  *   "split_small"      runs of small levels shaded per lane + resuming quads (1, default) | one quad launch (0)
+ *   "fuse"             a scene without meshes runs each level as one launch, closest hits and light loops (1, default) | two (0)
  *   "tiny_run"         a run of at most this many hits is shaded by one quad launch (default 8192)
  *   "tail_rays"        the deepest levels that together hold at most this many rays are traced by ONE launch, depth first
  *                      (k_tail), instead of a launch per level (0 = never)

@@ -100,6 +100,7 @@ struct Knobs {
     int order0 = 1;               // RT_ORDER0: level-0 launches of a small one-pass frame hand out their groups in descending order of the
                                   // previous frame's cost (k_order_groups); 0: pool order
     int split_small = 1;          // RT_SPLIT_SMALL: runs of small levels shaded per lane + resuming quads (1) / one quad launch (0)
+    int fuse = 1;                 // RT_FUSE: a scene without meshes runs a level's closest hits and light loops in ONE launch (k_trace_wide)
     int tiny_run = 8192;          // RT_TINY_RUN: a run of at most this many hits is one quad launch (the run that ends a pass - the tail's
                                   // hits, at most tail_rays of them - is on the frame's critical path: one 1080p frame at a time
                                   // 0.513-0.519 ms at 1024, 0.504-0.507 at 6000-16384, 0.509 at 40000)
@@ -137,6 +138,7 @@ static Knobs knobs_from_env() {
     k.sort_shade = std::max(0ll, env_ll("RT_SORT_SHADE", k.sort_shade));
     k.sort_bits = int(std::max(1ll, std::min(10ll, env_ll("RT_SORT_BITS", k.sort_bits))));
     k.tiny_run = int(std::max(0ll, env_ll("RT_TINY_RUN", k.tiny_run)));
+    k.fuse = int(env_ll("RT_FUSE", k.fuse)) ? 1 : 0;
     k.tail = std::max(0ll, env_ll("RT_TAIL", k.tail));
     k.index64 = std::getenv("RT_NO_FAST32") ? 1 : 0;
     k.chunk_log2 = int(std::min<long long>(RT_SHARD_CHUNK_LOG2_MAX, std::max(0ll, env_ll("RT_CHUNK_LOG2", k.chunk_log2))));
@@ -535,6 +537,7 @@ extern "C" int rt_scene_set_option(rt_scene* s, const char* name, int64_t value)
     else if (n == "shade_serve_level") k.shade_serve_lv = int(value);
     else if (n == "sort_shade") k.sort_shade = std::max<int64_t>(0, value);
     else if (n == "sort_bits") k.sort_bits = int(std::max<int64_t>(1, std::min<int64_t>(10, value)));
+    else if (n == "fuse") k.fuse = value ? 1 : 0;
     else if (n == "tiny_run") k.tiny_run = int(std::max<int64_t>(0, std::min<int64_t>(value, 1 << 30)));
     else if (n == "tail_rays") k.tail = std::max<int64_t>(0, value);
     else if (n == "index64") k.index64 = value ? 1 : 0;
@@ -1027,7 +1030,10 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
                     if ((rc = shade_small(small_lo, lv - 1, 2 * lv)) != RT_OK) return rc;
                     small_lo = -1;
                 }
-                if ((rc = timed_launch(J, sa, RT_K_EXTEND_WIDE, [&] { launch_extend(src, RT_FORM_WIDE, s->count_work, s->d, B, lv == 0 ? (B.order0 ? RT_ORDER_SLOTS(grid0) : grid0) : wide_grid_for(s, slot, lv, lv), sa); })) != RT_OK) return rc;
+                // a scene without meshes suspends nothing: the level's light loops in the same launch (k_trace_wide)
+                const bool fused = !meshes && s->knobs.fuse && !s->count_work && !wave_log;
+                if ((rc = timed_launch(J, sa, RT_K_EXTEND_WIDE, [&] { launch_extend(src, fused ? RT_FORM_WIDE_FUSED : RT_FORM_WIDE, s->count_work, s->d, B, lv == 0 ? (B.order0 ? RT_ORDER_SLOTS(grid0) : grid0) : wide_grid_for(s, slot, lv, lv), sa); })) != RT_OK) return rc;
+                if (fused) continue;
                 if (overlap) HIP_TRY(record(2 * lv));
                 // level 0 of a packet scene: the per-lane kernels traverse the meshes themselves, nothing is suspended
                 const bool quads = meshes && !((lv == 0 && s->d.packet) || s->d.packet >= 2);

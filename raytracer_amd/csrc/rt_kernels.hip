@@ -1377,11 +1377,12 @@ __device__ __forceinline__ bool fetch_ray(const LevelArgs& A, uint32_t begin, ui
 // level: the entry's recursion level (A.level in the level-synchronous kernels; per quad in k_tail). kids (or null):
 // the child rays and their pool entries, for a caller that goes on with them itself.
 struct Children { bool refl, refr; uint32_t i_refl, i_refr; Ray r_refl, r_refr; };
+struct FinishOut { uint4 rec_b; V3 hitPt; float rCoef; };      // what extend_finish stored for the entry (k_trace_wide shades it at once)
 #define NODE_LEVEL_SHIFT 8u      // node_b.w bits 8..11: the entry's recursion level (the `return red` exit un-counts children by level)
 __device__ __forceinline__ void extend_finish(const DScene& S, const LevelArgs& A, uint32_t i, bool active, bool valid,
                                               bool writer, const Ray& ray, const HitState& h, uint32_t next_base,
                                               uint32_t next_end, uint32_t* next_count, uint32_t extra_flags,
-                                              int level, Children* kids = nullptr) {
+                                              int level, Children* kids = nullptr, FinishOut* fo = nullptr) {
     uint4 rec_b = make_uint4(RT_NO_CHILD, RT_NO_CHILD, 0, 0);
     bool want_refl = false, want_refr = false;
     Ray r_refl, r_refr;
@@ -1465,8 +1466,10 @@ __device__ __forceinline__ void extend_finish(const DScene& S, const LevelArgs& 
         rec_b.w |= extra_flags | ((uint32_t)level << NODE_LEVEL_SHIFT);
         pool_st(A.node_b + i, rec_b);
         if (rec_b.w & NODE_HIT) {
-            pool_st(A.hit_n + i, make_float4(h.n.x, h.n.y, h.n.z, h.tmpdist));
-            pool_st(A.hit_p + i, make_float4(hitPt.x, hitPt.y, hitPt.z, rCoef));
+            if (!fo) {      // (k_trace_wide runs the light loop from registers)
+                pool_st(A.hit_n + i, make_float4(h.n.x, h.n.y, h.n.z, h.tmpdist));
+                pool_st(A.hit_p + i, make_float4(hitPt.x, hitPt.y, hitPt.z, rCoef));
+            }
         } else if (rec_b.w & NODE_VALID) {
             const u32x4 bg = ldc4(A.fp->background, 0);
             pool_st(A.node_a + i, make_float4(__uint_as_float(bg.x), __uint_as_float(bg.y), __uint_as_float(bg.z), 0));   // raytracer.cpp:302-304
@@ -1474,6 +1477,7 @@ __device__ __forceinline__ void extend_finish(const DScene& S, const LevelArgs& 
             A.node_a[i] = make_float4(0, 0, 0, 0);
         }
     }
+    if (fo) { fo->rec_b = rec_b; fo->hitPt = hitPt; fo->rCoef = rCoef; }
 }
 
 __device__ __forceinline__ HitState fresh_hit() {
@@ -1814,9 +1818,10 @@ __device__ __forceinline__ void flush_shadow(const LevelArgs& A, uint32_t n_shad
 
 // k_shade_wide: light loop, one hit per lane, for the hits of levels A.level..A.level_hi. Hits whose shadow rays never
 // reach a mesh are finished here; the others are queued (queue of A.level) at the point they stopped.
-// LEVEL0 (packets): 0 any level(s); 1 the launch is over level 0 and the kernel knows it (no range of levels, no queue, no
+// LEVEL0: 0 any level(s); 1 the launch is over level 0 and the kernel knows it (no range of levels, no queue, no
 // permutation: 6 SGPR spills and 6 VGPRs less - bunny_1080p in batches 0.2111 -> 0.2094 ms, shadows-only bunny 0.135 -> 0.133,
-// field at 1080p 3.94 -> 3.90, 4K glass scene 27.3 -> 26.6); 2 level 0, expensive groups first (ORDERED: see extend_wide_body).
+// field at 1080p 3.94 -> 3.90, 4K glass scene 27.3 -> 26.6; without packets 54 instead of 65 VGPRs, i.e. 8 waves per SIMD:
+// analytic 1080p 4 spp 0.361 -> 0.330); 2 level 0, expensive groups first (ORDERED: see extend_wide_body).
 template <bool COUNT, bool GPOW, int PACKET, int LEVEL0 = 0>
 __device__ __forceinline__ void shade_wide_body(const DScene& S, const LevelArgs& A_, uint32_t* lds) {
     const LevelArgs& A = A_;
@@ -1900,11 +1905,51 @@ __global__ __launch_bounds__(RT_WIDE_BLOCK_MAX) __attribute__((amdgpu_waves_per_
     extern __shared__ uint32_t pk_lds[];      // packet_traverse: the rays of a compacted leaf, RT_PK_LDS_WORDS per wave (dynamic: sized for the launch's waves)
     shade_wide_body<COUNT, GPOW, PACKET ? 1 : 0, LEVEL0>(S, A, PACKET ? pk_lds + (threadIdx.x >> 6) * RT_PK_LDS_WORDS : nullptr);
 }
+// k_trace_wide: one level of a scene WITHOUT meshes in one launch. Such a scene never suspends a ray, so nothing separates
+// the closest hit from its light loop: closest hit, Fresnel and child rays as k_extend_wide (extend_finish), then the light
+// loop of the hit as k_shade_wide (shade_ray) with the hit still in registers - the hit record (32 B written, 48 B read per
+// sample, the node record read again) never goes through memory, and the level is one launch instead of two on two
+// streams. The host launches it only for scenes that hold no Model (rt_api.cpp: option "fuse").
+// Measured (analytic scene, 1080p, 4 spp, shadows only, 8 frames per call): see DESIGN.md section 4.
+#ifndef RT_WPE_TW
+#define RT_WPE_TW 7
+#endif
+template <int SRC, bool GPOW>
+__global__ __launch_bounds__(RT_WIDE_BLOCK_MAX) __attribute__((amdgpu_waves_per_eu(GPOW ? 4 : RT_WPE_TW))) void k_trace_wide(DScene S, LevelArgs A) {
+    const bool level0 = SRC != 1;
+    const ShardView v = shard_view(A, A.level, A.level);
+    const Groups G = level0 ? make_groups_dense<false>(A.n0, A.chunk_log2) : make_groups<false>(v.start, v.cnt);
+    const uint32_t next_base_l = v.start + v.cnt;     // lane s: children of shard s are appended behind its level
+    Work wk = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t n_shadow = 0;
+    const uint32_t nwv = blockDim.x >> 6;      // see extend_wide_body
+    for (uint32_t w = blockIdx.x * nwv + (threadIdx.x >> 6); w < G.total; w += gridDim.x * nwv) {
+        uint32_t shard, pos, lim;
+        locate(G, w, shard, pos, lim);
+        const uint32_t i = pos + (threadIdx.x & 63u);
+        const bool active = i < lim;
+        Ray ray;
+        ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 0);
+        const bool valid = active && fetch_ray<SRC>(A, 0, i, ray);
+        HitState h = fresh_hit();
+        (void)closest_loop<false, false, 0>(S, ray, valid, 0, h, nullptr, wk, SRC == 0);      // (no Model in the scene: nothing suspends)
+        FinishOut fo;
+        extend_finish(S, A, i, active, valid, true, ray, h, lane_read(next_base_l, shard), A.n0 + (shard + 1u) * A.sub_cap,
+                      A.sc[shard].level + (A.level + 1), 0u, A.level, nullptr, &fo);
+        const bool hit = active && (fo.rec_b.w & NODE_HIT) != 0;
+        if (!__any(hit)) continue;                                                          // wave-uniform
+        int parked;
+        shade_ray<false, false, GPOW, 0>(S, A, i, fo.rec_b, hit, true, h.n, fo.hitPt, fo.rCoef, h.tmpdist, 0, 0, false, mk(0, 0, 0), nullptr, wk,
+                                         n_shadow, parked, SRC == 0);
+    }
+    flush_shadow(A, n_shadow);
+}
+
 // the hits of levels >= 1, one per lane, shadow rays through meshes by quad service
 template <bool COUNT, bool GPOW>
 __global__ __launch_bounds__(RT_BLOCK) __attribute__((amdgpu_waves_per_eu(RT_WPE_SS))) void k_shade_serve(DScene S, LevelArgs A) {
     __shared__ uint32_t lds_stack[RT_SERVE_LDS];
-    shade_wide_body<COUNT, GPOW, 2>(S, A, lds_stack);
+    shade_wide_body<COUNT, GPOW, 2>(S, A, lds_stack);      // (an instantiation that knows it is never level 0: no spills, measured no different)
 }
 
 // k_shade_quad: light loop, one hit per quad.
@@ -2630,6 +2675,13 @@ static void launch_extend_src(int form, bool count, const DScene& S, const Level
         } else {
             if (count) hipLaunchKernelGGL((k_extend_wide<SRC, true, false>), g, b, 0, st, S, A);
             else hipLaunchKernelGGL((k_extend_wide<SRC, false, false>), g, b, 0, st, S, A);
+        }
+    } else if (form == RT_FORM_WIDE_FUSED) {
+        if constexpr (SRC != 2) {       // (a scene without meshes: the level's light loops in the same launch)
+            b = dim3(64u * wide_waves());
+            g = dim3((g.x + wide_waves() - 1u) / wide_waves());
+            if (S.generic_pow) hipLaunchKernelGGL((k_trace_wide<SRC, true>), g, b, 0, st, S, A);
+            else hipLaunchKernelGGL((k_trace_wide<SRC, false>), g, b, 0, st, S, A);
         }
     } else if (form == RT_FORM_WIDE_SERVE) {
         if constexpr (SRC != 0) {       // (camera rays are never served: level 0 of a frame is packets or marks + quads)

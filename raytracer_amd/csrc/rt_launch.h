@@ -186,7 +186,9 @@ void launch_order_groups(uint32_t* cost_e, uint32_t* cost_s, uint32_t* order_e, 
 // RT_FORM_QUAD_PARKED (shade only): one hit per quad from the start, for the rays of the level's extend queue.
 // RT_FORM_WIDE_SERVE (levels >= 1): one ray / hit per lane like RT_FORM_WIDE, but nothing is suspended: the lanes whose ray
 // reaches a mesh are served 16 at a time by the wave's own quads (serve_traverse).
-enum { RT_FORM_WIDE = 0, RT_FORM_QUAD_FRESH = 1, RT_FORM_QUAD_RESUME = 2, RT_FORM_QUAD_PARKED = 3, RT_FORM_WIDE_SERVE = 4 };
+// RT_FORM_WIDE_FUSED (extend only; scenes without meshes, not the counting build): RT_FORM_WIDE and the level's light loops in one
+//   launch (k_trace_wide) - no shade launch follows.
+enum { RT_FORM_WIDE = 0, RT_FORM_QUAD_FRESH = 1, RT_FORM_QUAD_RESUME = 2, RT_FORM_QUAD_PARKED = 3, RT_FORM_WIDE_SERVE = 4, RT_FORM_WIDE_FUSED = 5 };
 void launch_extend(int src, int form, bool count, const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st);
 void launch_shade(int form, bool count, const DScene& S, const LevelArgs& A, uint32_t grid, hipStream_t st);
 void launch_set_frame_params(const FrameParamsBatch& p, uint32_t n_frames, FrameParams* dst, void* clear, size_t clear_bytes, hipStream_t st);   // clear: 16-byte multiple

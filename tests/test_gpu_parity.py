@@ -387,6 +387,38 @@ def test_traversal_forms_agree(spp_grid):
     assert np.array_equal(default_img, base[0]) and st.trace_calls == base[1]
 
 
+@pytest.mark.parametrize("gpow", [False, True])
+def test_fused_levels_agree(oracle_mod, gpow):
+    """A scene without meshes runs each recursion level as ONE launch (k_trace_wide: closest hits, child rays and the light
+    loops of the hits, the hit record never leaving the registers; option "fuse", on by default). Frames, ray counts and
+    level sizes equal those of the two-launch path (option "fuse" 0: k_extend_wide + k_shade_wide) and the oracle's, with
+    reflection and refraction down to depth 10, at 1 and 9 samples per pixel, with scene.yaml's integer exponents and with
+    the device pow, through the synchronous call and the asynchronous one into a device buffer."""
+    import torch
+    fs = wl.scene_analytic(third="glass2")
+    if gpow:
+        for m in fs.materials:
+            m.specRefExp = 7.5
+    cam = reference_camera(400, 300)
+    for p in (Params(), Params(aa=DEFAULT_AA, max_depth=6)):
+        fused, plain = DeviceScene(fs), DeviceScene(fs)
+        plain.set_option("fuse", 0)
+        a, st_a = fused.render(cam, p)
+        b, st_b = plain.render(cam, p)
+        assert np.array_equal(a, b)
+        assert (st_a.trace_calls, st_a.shadow_rays, list(st_a.level_rays)) == (st_b.trace_calls, st_b.shadow_rays, list(st_b.level_rays))
+        frame = torch.zeros((300, 400, 3), dtype=torch.uint8, device="cuda")
+        for _ in range(2):
+            fused.render_device(cam, p, frame.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+        fused.status()
+        torch.cuda.synchronize()
+        assert np.array_equal(frame.cpu().numpy(), a)
+        want, st_o = oracle_mod.Oracle(fs).render(cam, p)
+        within1, equal, worst = frame_stats(a, want)
+        assert within1 >= 0.999 and equal >= 0.9999
+        assert st_a.trace_calls == st_o.trace_calls and st_a.shadow_rays == st_o.shadow_rays
+
+
 def test_expensive_groups_first_agree():
     """Option "order0" (on by default): the level-0 launches of a small one-pass frame hand out their 64-sample groups in
     descending order of what they cost in the scene's previous frame, the most expensive as two halves or four quarters
