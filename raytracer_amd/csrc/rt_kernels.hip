@@ -1376,6 +1376,15 @@ __device__ __forceinline__ bool fetch_ray(const LevelArgs& A, uint32_t begin, ui
 // the per-lane kernels, lane 0 of the quad in the quad kernels). Called with the whole wave converged.
 // level: the entry's recursion level (A.level in the level-synchronous kernels; per quad in k_tail). kids (or null):
 // the child rays and their pool entries, for a caller that goes on with them itself.
+// node_a.w of an entry whose colour is FINAL (a miss, a hit without children, a folded node): a NaN no arithmetic produces.
+// node_color - and with it k_resolve, which reads every level-0 entry of the frame - then needs no look at node_b: 32 -> 16 B
+// per entry for the four pixels in five whose primary ray has no children. (Entries that still wait for their children keep
+// rCoef there, suspended light loops their tmpdist.)
+#ifndef RT_FINAL_MARK
+#define RT_FINAL_MARK 1      // (0: A/B builds)
+#endif
+#define RT_FINAL_W_BITS 0x7FFFA5A5u
+__device__ __forceinline__ float final_w(float otherwise) { return RT_FINAL_MARK ? __uint_as_float(RT_FINAL_W_BITS) : otherwise; }
 struct Children { bool refl, refr; uint32_t i_refl, i_refr; Ray r_refl, r_refr; };
 struct FinishOut { uint4 rec_b; V3 hitPt; float rCoef; };      // what extend_finish stored for the entry (k_trace_wide shades it at once)
 #define NODE_LEVEL_SHIFT 8u      // node_b.w bits 8..11: the entry's recursion level (the `return red` exit un-counts children by level)
@@ -1472,9 +1481,9 @@ __device__ __forceinline__ void extend_finish(const DScene& S, const LevelArgs& 
             }
         } else if (rec_b.w & NODE_VALID) {
             const u32x4 bg = ldc4(A.fp->background, 0);
-            pool_st(A.node_a + i, make_float4(__uint_as_float(bg.x), __uint_as_float(bg.y), __uint_as_float(bg.z), 0));   // raytracer.cpp:302-304
+            pool_st(A.node_a + i, make_float4(__uint_as_float(bg.x), __uint_as_float(bg.y), __uint_as_float(bg.z), final_w(0)));   // raytracer.cpp:302-304
         } else {
-            A.node_a[i] = make_float4(0, 0, 0, 0);
+            A.node_a[i] = make_float4(0, 0, 0, final_w(0));
         }
     }
     if (fo) { fo->rec_b = rec_b; fo->hitPt = hitPt; fo->rCoef = rCoef; }
@@ -1795,7 +1804,7 @@ __device__ __forceinline__ void shade_ray(const DScene& S, const LevelArgs& A_, 
     if (parked >= 0) {
         A.node_a[i] = make_float4(color.x, color.y, color.z, tmpdist);
     } else if (red) {
-        A.node_a[i] = make_float4(1, 0, 0, 0);
+        A.node_a[i] = make_float4(1, 0, 0, final_w(0));
         if (b.w & NODE_FOLD) {      // children were appended speculatively: ignore them, and un-count them
             A.node_b[i].w = b.w & ~NODE_FOLD;      // (the marks the level-0 quad kernels select by stay as they are)
             const int lv = (int)((b.w >> NODE_LEVEL_SHIFT) & 15u);      // the level of entry i
@@ -1806,7 +1815,7 @@ __device__ __forceinline__ void shade_ray(const DScene& S, const LevelArgs& A_, 
     } else {
         const rt_material m = *mp;
         const V3 c = finish_color(color, m, rCoef, mk(0, 0, 0), mk(0, 0, 0));
-        pool_st(A.node_a + i, make_float4(c.x, c.y, c.z, rCoef));
+        pool_st(A.node_a + i, make_float4(c.x, c.y, c.z, final_w(rCoef)));
     }
 }
 
@@ -2215,6 +2224,7 @@ __global__ __launch_bounds__(256) void k_sort_keys(DScene S, LevelArgs A, SortBo
 __device__ __forceinline__ V3 node_color(const DScene& S, const float4* __restrict__ node_a, const uint4* __restrict__ node_b,
                                          uint32_t i) {
     const float4 a = pool_ld(node_a + i);
+    if (RT_FINAL_MARK && __float_as_uint(a.w) == RT_FINAL_W_BITS) return mk(a.x, a.y, a.z);
     const uint4 b = pool_ld(node_b + i);
     if (!(b.w & NODE_FOLD)) return mk(a.x, a.y, a.z);
     const rt_material m = S.materials[b.z];
@@ -2262,9 +2272,7 @@ __device__ __forceinline__ void fold_body(const DScene& S, const LevelArgs& A, u
         const uint4 b = A.node_b[i];
         if (b.w & NODE_FOLD) {
             const V3 c = node_color(S, A.node_a, A.node_b, i);
-            float4 a = A.node_a[i];
-            a.x = c.x; a.y = c.y; a.z = c.z;
-            A.node_a[i] = a;
+            A.node_a[i] = make_float4(c.x, c.y, c.z, final_w(0));
             A.node_b[i].w = b.w & ~NODE_FOLD;
         }
     }
@@ -2369,9 +2377,7 @@ __global__ __launch_bounds__(64) void k_fold_tree(DScene S, LevelArgs A) {
                 continue;
             }
             const V3 c = node_color(S, A.node_a, A.node_b, i);
-            float4 a = A.node_a[i];
-            a.x = c.x; a.y = c.y; a.z = c.z;
-            A.node_a[i] = a;
+            A.node_a[i] = make_float4(c.x, c.y, c.z, final_w(0));
             A.node_b[i].w = b.w & ~NODE_FOLD;
             --sp;
         }
