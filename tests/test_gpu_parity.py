@@ -385,6 +385,15 @@ def test_traversal_forms_agree(spp_grid):
         assert f[1:] == base[1:], key
     default_img, st = DeviceScene(fs).render(cam, p)
     assert np.array_equal(default_img, base[0]) and st.trace_calls == base[1]
+    # option "run_hits": a run of small levels is shaded as soon as it holds that many hits (default 2^20: batches of
+    # frames) instead of when three levels have come together - here: every level by itself, with and without quad service
+    for serve in (0, 1):
+        dev = DeviceScene(fs)
+        dev.set_option("run_hits", 1)
+        dev.set_option("serve", serve)
+        dev.render(cam, p)
+        img, st = dev.render(cam, p)
+        assert np.array_equal(img, base[0]) and (st.trace_calls, st.shadow_rays, list(st.level_rays)) == base[1:]
 
 
 @pytest.mark.parametrize("gpow", [False, True])
