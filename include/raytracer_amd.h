@@ -351,7 +351,7 @@ int rt_scene_set_pass_samples(rt_scene* scene, uint32_t samples);
  *   "fuse"             a scene without meshes runs each level as one launch, closest hits and light loops (1, default) | two (0)
  *   "tiny_run"         a run of at most this many hits is shaded by one quad launch (default 8192)
  *   "run_hits"         a run of small levels that holds at least this many hits is shaded at once instead of when three levels have
- *                      come together (default 2^20; 0 = never)
+ *                      come together (default 786,432; 0 = never)
  *   "tail_rays"        the deepest levels that together hold at most this many rays are traced by ONE launch, depth first
  *                      (k_tail), instead of a launch per level (0 = never)
  *   "index64"          1: sample-index arithmetic by 64-bit division even where 32 bits would do

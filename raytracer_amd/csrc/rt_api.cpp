@@ -100,12 +100,15 @@ struct Knobs {
     int order0 = 1;               // RT_ORDER0: level-0 launches of a small one-pass frame hand out their groups in descending order of the
                                   // previous frame's cost (k_order_groups); 0: pool order
     int split_small = 1;          // RT_SPLIT_SMALL: runs of small levels shaded per lane + resuming quads (1) / one quad launch (0)
-    int run_hits = 1 << 20;       // RT_RUN_HITS: a run of small levels that holds at least this many hits is shaded at once, not when three levels
+    int run_hits = 3 << 18;       // RT_RUN_HITS: a run of small levels that holds at least this many hits is shaded at once, not when three levels
                                   // have come together (0: never). A call of 20 1080p frames: level 1 alone is 7.4 M hits, and their light
                                   // loops, started behind level 1's closest hits instead of level 3's, end before level 0's do instead of
                                   // 0.17 ms after them: 0.241 -> 0.224 ms per frame (250 k .. 4 M: 0.222-0.234); 4K glass scene 26.3 -> 25.1 ms;
                                   // 800x600 in batches 0.0635 -> 0.0622; two calls of 32 frames in flight: the same; the 10 M-triangle field
-                                  // at 1080p in batches 3.92 -> 3.98 (one frame at a time 4.58 -> 4.46)
+                                  // at 1080p in batches 3.92 -> 3.98 (one frame at a time 4.58 -> 4.46). Where it starts to pay, a rank's share
+                                  // of 10 tiled 1080p frames (tools/r3_run23.sh, threshold 250 k against never): a quarter of the tiles, level 1
+                                  // 0.92 M hits, 0.0835 -> 0.077 ms per frame; an eighth, 0.46 M, 0.050 -> 0.053; one whole frame, 0.37 M,
+                                  // 0.510 -> 0.527 - hence 3 x 2^18
     int fuse = 1;                 // RT_FUSE: a scene without meshes runs a level's closest hits and light loops in ONE launch (k_trace_wide)
     int tiny_run = 8192;          // RT_TINY_RUN: a run of at most this many hits is one quad launch (the run that ends a pass - the tail's
                                   // hits, at most tail_rays of them - is on the frame's critical path: one 1080p frame at a time
