@@ -582,8 +582,8 @@ def extras(args, out, dev, slots, fs, cam, cams, params, st, rays_per_frame, cam
     # (a scene without meshes runs a level as ONE launch, k_trace_wide: closest hits and light loops; its work is both kinds')
     fused0 = bool(n0[0] and not n0[1] and s0.shadow_rays)
     if fused0:
-        rocprof_names[0] = "k_trace_wide<0, false>"
-        rocprof_alt[0] = ["k_trace_wide<0, true>"]
+        rocprof_names[0] = f"k_trace_wide<0, false, {pk}, false>"
+        rocprof_alt[0] = ["k_trace_wide<0, true, false, false>", "k_trace_wide<0, false, true, true>"]
     dk = max(range(2), key=lambda k: ms0[k] / max(n0[k], 1))      # level 0 = the two per-lane launches
     avg_ms = ms0[dk] / n0[dk]
     launches = n0[dk] / reps                                       # per depth-0 frame = its passes

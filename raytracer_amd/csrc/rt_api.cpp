@@ -890,6 +890,12 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
         // groups - where a level-0 launch is mostly the drain of its longest waves - hands the groups out in descending order
         // of what they cost in the scene's previous frame of the same size. Not for the static pool (allocates) or a graph.
         const uint32_t n_grp0 = (A.n0 + 63u) / 64u;
+        // A scene with meshes none of whose materials bounces: level 0 is the whole frame and, as packets, suspends nothing -
+        // closest hits and light loops in ONE launch (k_trace_wide<0, false, PACKET>), in pixel order (measured, shadows-only bunny
+        // at 1080p, one frame at a time: two launches in pixel order 0.312 ms, expensive groups first 0.275, one launch 0.266; in
+        // batches 0.1313 -> 0.1295; the one launch with the expensive groups first - k_trace_wide<.., ORDERED>, a group's cost the whole
+        // of its wave: see DESIGN.md)
+        const bool fuse_l0 = meshes && !s->has_bounce && s->knobs.fuse && s->d.packet && !s->d.generic_pow && !s->count_work;
         bool order_on = s->knobs.order0 && px0 == 0 && done == 0 && npx <= pass_px && n_grp0 >= 2048u && n_grp0 <= RT_ORDER_MAX_GROUPS &&
                         s->d.packet && !s->d.generic_pow && !s->count_work &&      // (the kernels that log and follow an order: k_extend_wide / k_shade_wide <.., ORDERED>)
                         s->knobs.grid0 == 0 && !J.noalloc && !s->knobs.use_graph && ensure_order_buf(s, n_grp0, sa);
@@ -1045,7 +1051,8 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
                     small_lo = -1;
                 }
                 // a scene without meshes suspends nothing: the level's light loops in the same launch (k_trace_wide)
-                const bool fused = !meshes && s->knobs.fuse && !s->count_work && !wave_log;
+                // (... and so does level 0 as packets, where it is the whole frame: no material bounces)
+                const bool fused = (!meshes || fuse_l0) && s->knobs.fuse && !s->count_work && !wave_log;
                 if ((rc = timed_launch(J, sa, RT_K_EXTEND_WIDE, [&] { launch_extend(src, fused ? RT_FORM_WIDE_FUSED : RT_FORM_WIDE, s->count_work, s->d, B, lv == 0 ? (B.order0 ? RT_ORDER_SLOTS(grid0) : grid0) : wide_grid_for(s, slot, lv, lv), sa); })) != RT_OK) return rc;
                 if (fused) continue;
                 if (overlap) HIP_TRY(record(2 * lv));
@@ -1110,6 +1117,10 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
             // stream of its own - a fifth per scene - one frame at a time got slower, 0.555 -> 0.567 ms: the streams share
             // four hardware queues.)
             hipStream_t so = overlap ? s->shade_stream[0] : sa;
+            if (fuse_l0 && overlap) {      // (one launch did the level on stream A: the light-loop stream has nothing of this frame to follow)
+                HIP_TRY(hipEventRecord(s->ev_sync[2 * RT_MAX_LEVELS + 4], sa));
+                HIP_TRY(hipStreamWaitEvent(so, s->ev_sync[2 * RT_MAX_LEVELS + 4], 0));
+            }
             launch_order_groups(s->cost0[0], s->cost0[1], s->order0[0], s->order0[1],
                                 reinterpret_cast<uint8_t*>(s->order0[0] + RT_ORDER_SLOTS(s->order_cap)),
                                 reinterpret_cast<uint8_t*>(s->order0[1] + RT_ORDER_SLOTS(s->order_cap)), n_grp0, so);

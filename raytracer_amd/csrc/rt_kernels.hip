@@ -1923,8 +1923,13 @@ __global__ __launch_bounds__(RT_WIDE_BLOCK_MAX) __attribute__((amdgpu_waves_per_
 #ifndef RT_WPE_TW
 #define RT_WPE_TW 7
 #endif
-template <int SRC, bool GPOW>
+// PACKET (level 0 only): a scene WITH meshes none of whose materials bounces - level 0 is the whole frame, and as packets
+// level 0 suspends nothing either (closest hits and shadow rays traverse the mesh in the per-lane kernel itself).
+// ORDERED (with PACKET): expensive groups first as in extend_wide_body - a group's cost is the whole of its wave here.
+template <int SRC, bool GPOW, bool PACKET = false, bool ORDERED = false>
 __global__ __launch_bounds__(RT_WIDE_BLOCK_MAX) __attribute__((amdgpu_waves_per_eu(GPOW ? 4 : RT_WPE_TW))) void k_trace_wide(DScene S, LevelArgs A) {
+    extern __shared__ uint32_t pk_lds[];      // (packet_traverse: see k_shade_wide)
+    uint32_t* lds = PACKET ? pk_lds + (threadIdx.x >> 6) * RT_PK_LDS_WORDS : nullptr;
     const bool level0 = SRC != 1;
     const ShardView v = shard_view(A, A.level, A.level);
     const Groups G = level0 ? make_groups_dense<false>(A.n0, A.chunk_log2) : make_groups<false>(v.start, v.cnt);
@@ -1932,24 +1937,34 @@ __global__ __launch_bounds__(RT_WIDE_BLOCK_MAX) __attribute__((amdgpu_waves_per_
     Work wk = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t n_shadow = 0;
     const uint32_t nwv = blockDim.x >> 6;      // see extend_wide_body
-    for (uint32_t w = blockIdx.x * nwv + (threadIdx.x >> 6); w < G.total; w += gridDim.x * nwv) {
+    const bool ordered = ORDERED && A.order0;      // (wave-uniform)
+    const uint32_t n_w = ordered ? RT_ORDER_SLOTS(G.total) : G.total;
+    for (uint32_t w = blockIdx.x * nwv + (threadIdx.x >> 6); w < n_w; w += gridDim.x * nwv) {
+        const uint32_t code = ordered ? ((const RT_CONSTANT uint32_t*)(const void*)A.order0)[w] : w;
+        if (ORDERED && code == RT_ORDER_NONE) continue;                                        // wave-uniform
+        const uint32_t grp = ordered ? (code & 0x0FFFFFFFu) : code, parts_log2 = ordered ? ((code >> 28) & 3u) : 0u, part = ordered ? (code >> 30) : 0u;
+        if (ORDERED && grp >= G.total) continue;                                               // (an order is only ever a hint: never out of range)
+        const unsigned long long t_grp = (ORDERED && A.cost0) ? wall_clock64() : 0ull;
         uint32_t shard, pos, lim;
-        locate(G, w, shard, pos, lim);
+        locate(G, grp, shard, pos, lim);
         const uint32_t i = pos + (threadIdx.x & 63u);
-        const bool active = i < lim;
+        const bool active = i < lim && (!ORDERED || ((threadIdx.x & 63u) >> (6u - parts_log2)) == part);
         Ray ray;
         ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 0);
         const bool valid = active && fetch_ray<SRC>(A, 0, i, ray);
         HitState h = fresh_hit();
-        (void)closest_loop<false, false, 0>(S, ray, valid, 0, h, nullptr, wk, SRC == 0);      // (no Model in the scene: nothing suspends)
+        (void)closest_loop<false, false, PACKET ? 1 : 0>(S, ray, valid, 0, h, lds, wk, SRC == 0);      // (no Model in the scene, or packets: nothing suspends)
         FinishOut fo;
         extend_finish(S, A, i, active, valid, true, ray, h, lane_read(next_base_l, shard), A.n0 + (shard + 1u) * A.sub_cap,
                       A.sc[shard].level + (A.level + 1), 0u, A.level, nullptr, &fo);
         const bool hit = active && (fo.rec_b.w & NODE_HIT) != 0;
-        if (!__any(hit)) continue;                                                          // wave-uniform
-        int parked;
-        shade_ray<false, false, GPOW, 0>(S, A, i, fo.rec_b, hit, true, h.n, fo.hitPt, fo.rCoef, h.tmpdist, 0, 0, false, mk(0, 0, 0), nullptr, wk,
-                                         n_shadow, parked, SRC == 0);
+        if (__any(hit)) {                                                                   // wave-uniform
+            int parked;
+            shade_ray<false, false, GPOW, PACKET ? 1 : 0>(S, A, i, fo.rec_b, hit, true, h.n, fo.hitPt, fo.rCoef, h.tmpdist, 0, 0, false, mk(0, 0, 0), lds, wk,
+                                                          n_shadow, parked, SRC == 0);
+        }
+        if (ORDERED && A.cost0 && lane_id() == 0)      // (the word of the wave's first quarter; a group that was not split: word 0)
+            A.cost0[4u * grp + (part << (2u - parts_log2))] = (uint32_t)min(wall_clock64() - t_grp, 0xFFFFull);
     }
     flush_shadow(A, n_shadow);
 }
@@ -2686,7 +2701,9 @@ static void launch_extend_src(int form, bool count, const DScene& S, const Level
         if constexpr (SRC != 2) {       // (a scene without meshes: the level's light loops in the same launch)
             b = dim3(64u * wide_waves());
             g = dim3((g.x + wide_waves() - 1u) / wide_waves());
-            if (S.generic_pow) hipLaunchKernelGGL((k_trace_wide<SRC, true>), g, b, 0, st, S, A);
+            if (SRC == 0 && S.packet && !S.generic_pow && A.cost0) hipLaunchKernelGGL((k_trace_wide<0, false, true, true>), g, b, RT_LEAF_COMPACT ? wide_waves() * RT_PK_LDS_WORDS * 4u : 0u, st, S, A);
+            else if (SRC == 0 && S.packet && !S.generic_pow) hipLaunchKernelGGL((k_trace_wide<0, false, true>), g, b, RT_LEAF_COMPACT ? wide_waves() * RT_PK_LDS_WORDS * 4u : 0u, st, S, A);
+            else if (S.generic_pow) hipLaunchKernelGGL((k_trace_wide<SRC, true>), g, b, 0, st, S, A);
             else hipLaunchKernelGGL((k_trace_wide<SRC, false>), g, b, 0, st, S, A);
         }
     } else if (form == RT_FORM_WIDE_SERVE) {

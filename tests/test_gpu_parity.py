@@ -428,6 +428,36 @@ def test_fused_levels_agree(oracle_mod, gpow):
         assert st_a.trace_calls == st_o.trace_calls and st_a.shadow_rays == st_o.shadow_rays
 
 
+@pytest.mark.parametrize("spheres", [False, True])
+def test_fused_level0_packets_agree(oracle_mod, spheres):
+    """A scene WITH a mesh none of whose materials bounces (BASELINE config 3: Phong + hard shadows): level 0 is the whole
+    frame and, as packets, suspends nothing - closest hits and light loops run in one launch (k_trace_wide<0, false, PACKET>;
+    option "fuse"). Frames and ray counts equal the two-launch path's (option "fuse" 0, with and without the expensive-groups
+    order) and the oracle's, at 1 and 4 samples per pixel, single frames, a batch, and the asynchronous call."""
+    import torch
+    fs = wl.scene_bunny(10, shadows_only=True, spheres=spheres)
+    cam = reference_camera(448, 320)      # 2240 groups of 64 samples: the two-launch path orders them
+    for p in (Params(), Params(aa=wl.aa_grid(2))):
+        fused, plain = DeviceScene(fs), DeviceScene(fs)
+        plain.set_option("fuse", 0)
+        a, st_a = fused.render(cam, p)
+        for _ in range(3):      # (the second and third frame of `plain` follow the first one's costs)
+            b, st_b = plain.render(cam, p)
+            assert np.array_equal(a, b)
+            assert (st_a.trace_calls, st_a.shadow_rays) == (st_b.trace_calls, st_b.shadow_rays)
+        frames = torch.zeros((3, 320, 448, 3), dtype=torch.uint8, device="cuda")
+        stream = torch.cuda.Stream()
+        fused.render_batch_device([cam] * 3, p, frames.data_ptr(), 320 * 448 * 3, stream=stream.cuda_stream)
+        fused.status()
+        torch.cuda.synchronize()
+        for k in range(3):
+            assert np.array_equal(frames[k].cpu().numpy(), a)
+        want, st_o = oracle_mod.Oracle(fs).render(cam, p)
+        within1, equal, worst = frame_stats(a, want)
+        assert within1 >= 0.999 and equal >= 0.9999
+        assert st_a.trace_calls == st_o.trace_calls and st_a.shadow_rays == st_o.shadow_rays
+
+
 def test_expensive_groups_first_agree():
     """Option "order0" (on by default): the level-0 launches of a small one-pass frame hand out their 64-sample groups in
     descending order of what they cost in the scene's previous frame, the most expensive as two halves or four quarters
