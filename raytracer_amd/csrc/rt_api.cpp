@@ -243,12 +243,21 @@ struct rt_scene {
     SortBuf sort_buf[3];
     // expensive groups first (k_order_groups): per-group cost of the level-0 closest-hit [0] and light-loop [1] launch of the
     // most recent small one-pass frame, and the group numbers in descending order of it for the next one
-    uint32_t* cost0[2] = {nullptr, nullptr};
-    uint32_t* order0[2] = {nullptr, nullptr};
-    uint32_t order_cap = 0;              // groups the four arrays hold
-    uint32_t order_n = 0;                // groups the current order was made for (0: none yet)
-    hipEvent_t ev_ordered = nullptr;     // recorded behind k_order_groups; the next frame asks whether it has happened
-    bool order_pending = false;
+    // TWO sets, taken in turn: a frame logs its costs into its set, follows the order that set holds - made by the frame before
+    // the previous one - and leaves its own order there. The ordering kernel runs behind the frame and is not part of what the
+    // frame waits for; with one set the NEXT frame found it still running whenever a frame ends right behind level 0 (no
+    // bounce levels) and went in pixel order, every other frame. With two, the kernel a frame asks about was launched two
+    // frames ago.
+    struct OrderSet {
+        uint32_t* cost[2] = {nullptr, nullptr};
+        uint32_t* order[2] = {nullptr, nullptr};
+        uint32_t n = 0;                  // groups the set's order was made for (0: none yet)
+        hipEvent_t ev = nullptr;         // recorded behind k_order_groups; a later frame asks whether it has happened
+        bool pending = false;
+    };
+    OrderSet oset[2];
+    uint32_t order_turn = 0;             // frames that took a set so far
+    uint32_t order_cap = 0;              // groups the arrays hold
     SortBox sort_box{};
     bool sort_box_ok = false;
 };
@@ -261,8 +270,10 @@ static int free_scene(rt_scene* s) {
     for (void* p : s->owned) hipFree(p);
     hipFree(s->node_a); hipFree(s->node_b); hipFree(s->rays); hipFree(s->hit_n); hipFree(s->hit_p); hipFree(s->queue_e); hipFree(s->queue_s); hipFree(s->d_counters); hipFree(s->d_aa); hipFree(s->d_frame);
     hipFree(s->d_host_frames[0]); hipFree(s->d_host_frames[1]);
-    hipFree(s->cost0[0]); hipFree(s->cost0[1]); hipFree(s->order0[0]); hipFree(s->order0[1]);
-    if (s->ev_ordered) hipEventDestroy(s->ev_ordered);
+    for (auto& o : s->oset) {
+        hipFree(o.cost[0]); hipFree(o.cost[1]); hipFree(o.order[0]); hipFree(o.order[1]);
+        if (o.ev) hipEventDestroy(o.ev);
+    }
     for (auto& b : s->sort_buf) { hipFree(b.keys[0]); hipFree(b.keys[1]); hipFree(b.vals[0]); hipFree(b.vals[1]); hipFree(b.temp); }
     for (int k = 0; k < 2; ++k) { if (s->ev_rendered[k]) hipEventDestroy(s->ev_rendered[k]); if (s->ev_copied[k]) hipEventDestroy(s->ev_copied[k]); }
     if (s->copy_stream) hipStreamDestroy(s->copy_stream);
@@ -543,7 +554,7 @@ extern "C" int rt_scene_set_option(rt_scene* s, const char* name, int64_t value)
     else if (n == "large_max_level") k.large_maxlv = value < 0 ? -1 : int(std::min<int64_t>(value, RT_MAX_LEVELS));
     else if (n == "serve") k.serve = value < 0 ? -1 : (value ? 1 : 0);
     else if (n == "split_small") k.split_small = value ? 1 : 0;
-    else if (n == "order0") { k.order0 = value ? 1 : 0; s->order_n = 0; }
+    else if (n == "order0") { k.order0 = value ? 1 : 0; s->oset[0].n = s->oset[1].n = 0; }
     else if (n == "shade_serve_level") k.shade_serve_lv = int(value);
     else if (n == "sort_shade") k.sort_shade = std::max<int64_t>(0, value);
     else if (n == "sort_bits") k.sort_bits = int(std::max<int64_t>(1, std::min<int64_t>(10, value)));
@@ -782,21 +793,29 @@ static uint32_t wide_grid_for(const rt_scene* s, uint32_t pass, int lo, int hi) 
 
 // Arrays of the expensive-groups-first order for at least n groups (grow-only). false: no memory - pool order then.
 static bool ensure_order_buf(rt_scene* s, uint32_t n, hipStream_t st) {
-    if (s->order_cap >= n && s->ev_ordered) return true;
+    if (s->order_cap >= n && s->oset[0].ev && s->oset[1].ev) return true;
     if (s->order_cap) (void)hipDeviceSynchronize();      // (a frame in flight may still use the old ones)
-    for (int k = 0; k < 2; ++k) { hipFree(s->cost0[k]); hipFree(s->order0[k]); s->cost0[k] = s->order0[k] = nullptr; }
-    s->order_cap = 0; s->order_n = 0; s->order_pending = false;
+    auto release = [&] {
+        for (auto& o : s->oset)
+            for (int k = 0; k < 2; ++k) { hipFree(o.cost[k]); hipFree(o.order[k]); o.cost[k] = o.order[k] = nullptr; }
+    };
+    release();
+    s->order_cap = 0;
     const uint32_t cap = std::max<uint32_t>(n, 1u << 15);
-    bool ok = s->ev_ordered || hipEventCreateWithFlags(&s->ev_ordered, hipEventDisableTiming) == hipSuccess;
-    for (int k = 0; k < 2; ++k) {      // (costs: 4 words per group, cleared once here and then by k_order_groups)
-        ok = ok && hipMalloc(reinterpret_cast<void**>(&s->cost0[k]), size_t(cap) * 16u) == hipSuccess;
-        // (on the frame's stream: a plain hipMemset runs on the null stream, which the scene's non-blocking streams do not wait for)
-        ok = ok && hipMemsetAsync(s->cost0[k], 0, size_t(cap) * 16u, st) == hipSuccess;
-        ok = ok && hipMalloc(reinterpret_cast<void**>(&s->order0[k]), size_t(RT_ORDER_SLOTS(cap)) * 4u + cap) == hipSuccess;      // + k_order_groups' keys
+    bool ok = true;
+    for (auto& o : s->oset) {
+        o.n = 0; o.pending = false;
+        ok = ok && (o.ev || hipEventCreateWithFlags(&o.ev, hipEventDisableTiming) == hipSuccess);
+        for (int k = 0; k < 2; ++k) {      // (costs: 4 words per group, cleared once here and then by k_order_groups)
+            ok = ok && hipMalloc(reinterpret_cast<void**>(&o.cost[k]), size_t(cap) * 16u) == hipSuccess;
+            // (on the frame's stream: a plain hipMemset runs on the null stream, which the scene's non-blocking streams do not wait for)
+            ok = ok && hipMemsetAsync(o.cost[k], 0, size_t(cap) * 16u, st) == hipSuccess;
+            ok = ok && hipMalloc(reinterpret_cast<void**>(&o.order[k]), size_t(RT_ORDER_SLOTS(cap)) * 4u + cap) == hipSuccess;      // + k_order_groups' keys
+        }
     }
     if (!ok) {
         (void)hipGetLastError();
-        for (int k = 0; k < 2; ++k) { hipFree(s->cost0[k]); hipFree(s->order0[k]); s->cost0[k] = s->order0[k] = nullptr; }
+        release();
         return false;
     }
     s->order_cap = cap;
@@ -901,13 +920,14 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
                         s->knobs.grid0 == 0 && !J.noalloc && !s->knobs.use_graph && ensure_order_buf(s, n_grp0, sa);
         const uint32_t* order_e = nullptr;
         const uint32_t* order_s = nullptr;
-        if (order_on && s->order_pending) {
+        rt_scene::OrderSet& O = s->oset[s->order_turn & 1u];      // this frame's set
+        if (order_on && O.pending) {
             // the previous frame's k_order_groups is not part of what that frame waits for: when it has not finished yet (a frame
             // whose level-0 light loops are the last thing it does), this frame neither waits for it nor touches its arrays
-            if (hipEventQuery(s->ev_ordered) == hipSuccess) s->order_pending = false;
+            if (hipEventQuery(O.ev) == hipSuccess) O.pending = false;
             else { (void)hipGetLastError(); order_on = false; }
         }
-        if (order_on && s->order_n == n_grp0) { order_e = s->order0[0]; order_s = s->order0[1]; }
+        if (order_on && O.n == n_grp0) { order_e = O.order[0]; order_s = O.order[1]; }
         int rc;
         bool used_shade[3] = {false, false, false};
         // a shade stream waits for an event once per RECORDING of it: slots are re-recorded within a pass (ev_sync[2*lv]
@@ -952,7 +972,7 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
                 LevelArgs B = A;
                 B.level = part == 0 ? 0 : (lo == 0 && hi > 0 ? 1 : lo);
                 B.level_hi = part == 0 ? 0 : hi;
-                if (order_on && B.level_hi == 0 && form == RT_FORM_WIDE) { B.order0 = order_s; B.cost0 = s->cost0[1]; }
+                if (order_on && B.level_hi == 0 && form == RT_FORM_WIDE) { B.order0 = order_s; B.cost0 = O.cost[1]; }
                 B.wave_log = (log_shade && B.level == log_level) ? wave_log : nullptr;
                 const bool wide = form == RT_FORM_WIDE || form == RT_FORM_WIDE_SERVE;
                 const uint32_t wide_grid = wide ? wide_grid_for(s, slot, B.level, B.level_hi) : RT_LEVEL_GRID;
@@ -1040,7 +1060,7 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
             }
             LevelArgs B = A;
             B.level = lv; B.level_hi = lv;
-            if (order_on && lv == 0) { B.order0 = order_e; B.cost0 = s->cost0[0]; }
+            if (order_on && lv == 0) { B.order0 = order_e; B.cost0 = O.cost[0]; }
             const int src = lv == 0 ? 0 : 1;
             const bool large = !meshes || lv == 0 || expect_large(s, slot, lv, lv);
             B.wave_log = (lv == log_level && !log_shade) ? wave_log : nullptr;
@@ -1121,12 +1141,13 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
                 HIP_TRY(hipEventRecord(s->ev_sync[2 * RT_MAX_LEVELS + 4], sa));
                 HIP_TRY(hipStreamWaitEvent(so, s->ev_sync[2 * RT_MAX_LEVELS + 4], 0));
             }
-            launch_order_groups(s->cost0[0], s->cost0[1], s->order0[0], s->order0[1],
-                                reinterpret_cast<uint8_t*>(s->order0[0] + RT_ORDER_SLOTS(s->order_cap)),
-                                reinterpret_cast<uint8_t*>(s->order0[1] + RT_ORDER_SLOTS(s->order_cap)), n_grp0, so);
-            HIP_TRY(hipEventRecord(s->ev_ordered, so));
-            s->order_pending = true;
-            s->order_n = n_grp0;
+            launch_order_groups(O.cost[0], O.cost[1], O.order[0], O.order[1],
+                                reinterpret_cast<uint8_t*>(O.order[0] + RT_ORDER_SLOTS(s->order_cap)),
+                                reinterpret_cast<uint8_t*>(O.order[1] + RT_ORDER_SLOTS(s->order_cap)), n_grp0, so);
+            HIP_TRY(hipEventRecord(O.ev, so));
+            O.pending = true;
+            O.n = n_grp0;
+            ++s->order_turn;
         }
         // (folding the deep levels, which hold few nodes, by ONE workgroup in one launch was measured again with the sharded
         // pool: 85 us against 9 launches x 5 us, 0.706 vs 0.686 ms/frame)
