@@ -358,7 +358,7 @@ int rt_scene_set_pass_samples(rt_scene* scene, uint32_t samples);
  *   "chunk_log2"       level-0 blocks per shard chunk
  *   "graph"            1: asynchronous frames are captured into a hipGraph and replayed (measured slower)
  *   "order0"           1 (default): the level-0 launches of a one-pass frame of 2,048 to 65,536 64-sample groups hand the groups
- *                      out in descending order of what they cost in the scene's previous frame, the dearest in parts
+ *                      out in descending order of what they cost two frames earlier (two sets of arrays in turn), the dearest in parts
  *                      (k_order_groups); 0: pool order
  *   "shade_serve_level" with packets below level 0: the light loops of large levels >= this one by quad service instead of
  *                      packets (0, default: packets; measured slower)
