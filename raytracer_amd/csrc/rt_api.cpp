@@ -1008,7 +1008,11 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
         // The hits of a run of small levels lo..hi (extended as whole rays by the quad kernel): the light loops' analytic
         // objects and the Phong terms one hit per LANE (a quad kernel computes them four times over), the shadow rays that
         // reach a mesh queued and resumed by quads: 39 M -> 23 M VALU instructions per 1080p frame.
-        // Bounce levels of a pass that fills the chip by itself (4 M samples and more: a batch of frames, a 4K frame) are
+        // (Where the pass-size rule switches, measured again at round 3's kernels, bunny_1080p, two calls in flight, quads / quad
+        // service: 3 frames per call - 6.2 M samples - 0.287 / 0.307 ms per frame, 4 frames 0.265 / 0.268, 6 frames 0.253 / 0.245; a
+        // rank's quarter of ten tiled frames, 5.2 M, 0.073 / 0.077; its half, 10.4 M, the same; 12 frames of 800x600, 5.8 M, 0.0762 /
+        // 0.0776: from 10 M samples on - it was 4 M.)
+        // Bounce levels of a pass that fills the chip by itself (10 M samples and more: a batch of frames, a 4K frame) are
         // bound by instruction issue, not by the length of their waves: there the per-lane kernels with quad service do
         // extend and shade (fewest instructions: bunny_1080p in batches 0.326 -> 0.302 ms, c1 0.089 -> 0.080, 10 M-triangle
         // field 5.40 -> 5.22); a smaller pass keeps one ray per quad, whose waves are a quarter as long (one 1080p frame at
@@ -1016,7 +1020,7 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
         const int serve_env = s->knobs.serve;
             // (Scenes with packets at every level, 16+ spp: their small bounce levels only from 32 M-sample passes on - 4K glass
         // scene at 2^26 32.0 -> 31.0 ms, at 2^25 34.1 -> 33.1; 10 M-triangle field at 8K: 2^23 632 -> 673 ms, 2^26 the same.)
-        const bool serve = s->d.packet >= 1 && (serve_env >= 0 ? serve_env != 0 : (A.n0 >= (s->d.packet == 1 ? (4u << 20) : (32u << 20))));
+        const bool serve = s->d.packet >= 1 && (serve_env >= 0 ? serve_env != 0 : (A.n0 >= (s->d.packet == 1 ? (10u << 20) : (32u << 20))));
         const bool split_small = s->knobs.split_small != 0;
         auto shade_small_run = [&](int lo, int hi, int after) -> int {
             // (not where the per-lane kernels traverse meshes as packets at every level: the rays of a small bounce level
