@@ -100,6 +100,7 @@ struct Knobs {
     int order0 = 1;               // RT_ORDER0: level-0 launches of a small one-pass frame hand out their groups in descending order of the
                                   // previous frame's cost (k_order_groups); 0: pool order
     int split_small = 1;          // RT_SPLIT_SMALL: runs of small levels shaded per lane + resuming quads (1) / one quad launch (0)
+    int wide_waves_small = 4;     // RT_WIDE_WAVES_SMALL: waves per workgroup of the per-lane launches of a pass below the quad-service size (0: the default, one)
     int run_hits = 3 << 18;       // RT_RUN_HITS: a run of small levels that holds at least this many hits is shaded at once, not when three levels
                                   // have come together (0: never). A call of 20 1080p frames: level 1 alone is 7.4 M hits, and their light
                                   // loops, started behind level 1's closest hits instead of level 3's, end before level 0's do instead of
@@ -149,6 +150,7 @@ static Knobs knobs_from_env() {
     k.tiny_run = int(std::max(0ll, env_ll("RT_TINY_RUN", k.tiny_run)));
     k.fuse = int(env_ll("RT_FUSE", k.fuse)) ? 1 : 0;
     k.run_hits = int(std::max(0ll, env_ll("RT_RUN_HITS", k.run_hits)));
+    k.wide_waves_small = int(std::max(0ll, std::min(4ll, env_ll("RT_WIDE_WAVES_SMALL", k.wide_waves_small))));
     k.tail = std::max(0ll, env_ll("RT_TAIL", k.tail));
     k.index64 = std::getenv("RT_NO_FAST32") ? 1 : 0;
     k.chunk_log2 = int(std::min<long long>(RT_SHARD_CHUNK_LOG2_MAX, std::max(0ll, env_ll("RT_CHUNK_LOG2", k.chunk_log2))));
@@ -1021,6 +1023,13 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
             // (Scenes with packets at every level, 16+ spp: their small bounce levels only from 32 M-sample passes on - 4K glass
         // scene at 2^26 32.0 -> 31.0 ms, at 2^25 34.1 -> 33.1; 10 M-triangle field at 8K: 2^23 632 -> 673 ms, 2^26 the same.)
         const bool serve = s->d.packet >= 1 && (serve_env >= 0 ? serve_env != 0 : (A.n0 >= (s->d.packet == 1 ? (10u << 20) : (32u << 20))));
+        // Waves per workgroup of the pass' per-lane launches: four where the frame comes alone and has bounce levels (a pass of at
+        // most 4 M samples), one everywhere else. Measured (RT_WIDE_BLOCK 64 / 256 for every launch): bunny_1080p one frame at a
+        // time 0.511 -> 0.484 ms, rt_render into host memory 0.656 -> 0.632, in batches 0.210 -> 0.224; 800x600 0.340 -> 0.336;
+        // shadows-only bunny (no bounce levels) 0.206 -> 0.213.
+        // (A single frame of the 10 M-triangle field at 1080p 4 spp, 8.3 M samples: 4.63 -> 5.03 ms with four - hence up to 4 M samples;
+        // a rank's eighth of ten tiled frames, 2.6 M: 0.0503 -> 0.0484 ms per frame.)
+        A.wide_waves = (s->knobs.wide_waves_small > 0 && s->has_bounce && meshes && !serve && A.n0 <= (4u << 20)) ? uint32_t(s->knobs.wide_waves_small) : 0u;
         const bool split_small = s->knobs.split_small != 0;
         auto shade_small_run = [&](int lo, int hi, int after) -> int {
             // (not where the per-lane kernels traverse meshes as packets at every level: the rays of a small bounce level

@@ -2679,16 +2679,22 @@ hipError_t noalloc_scratch(int device, void** ptr) {
 extern "C++" {
 
 // Waves per workgroup of the per-lane kernels (RT_WIDE_BLOCK in the environment: threads, for experiments).
-static uint32_t wide_waves() {
+static uint32_t wide_waves_default() {
     static const uint32_t n = [] { const char* e = std::getenv("RT_WIDE_BLOCK"); const int t = e ? std::atoi(e) : RT_WIDE_BLOCK_DEFAULT; return (uint32_t)std::max(1, std::min(RT_WIDE_BLOCK_MAX, t) / 64); }();
     return n;
+}
+// ... of this launch: the pass' choice (LevelArgs::wide_waves: rt_api.cpp picks 4 for the passes of frames that come alone) or
+// the process default above.
+static uint32_t wide_waves_of(const LevelArgs& A) {
+    const uint32_t w = A.wide_waves ? A.wide_waves : wide_waves_default();
+    return std::max(1u, std::min<uint32_t>(w, RT_WIDE_BLOCK_MAX / 64));
 }
 template <int SRC>
 static void launch_extend_src(int form, bool count, const DScene& S, const LevelArgs& A, dim3 g, hipStream_t st) {
     dim3 b(RT_BLOCK);
     if (form == RT_FORM_WIDE) {
-        b = dim3(64u * wide_waves());
-        g = dim3((g.x + wide_waves() - 1u) / wide_waves());
+        b = dim3(64u * wide_waves_of(A));
+        g = dim3((g.x + wide_waves_of(A) - 1u) / wide_waves_of(A));
         if ((SRC == 0 && S.packet) || (SRC == 1 && S.packet >= 2) || (SRC == 2 && S.user_packet)) {     // primary rays: coherent, traversed as packets in the per-lane kernel itself (2: deeper levels too; user_packet: rt_trace_form)
             if (count) hipLaunchKernelGGL((k_extend_wide<SRC, true, true>), g, b, 0, st, S, A);
             else if (SRC == 0 && A.cost0) hipLaunchKernelGGL((k_extend_wide<0, false, true, true>), g, b, 0, st, S, A);      // expensive groups first
@@ -2699,10 +2705,10 @@ static void launch_extend_src(int form, bool count, const DScene& S, const Level
         }
     } else if (form == RT_FORM_WIDE_FUSED) {
         if constexpr (SRC != 2) {       // (a scene without meshes: the level's light loops in the same launch)
-            b = dim3(64u * wide_waves());
-            g = dim3((g.x + wide_waves() - 1u) / wide_waves());
-            if (SRC == 0 && S.packet && !S.generic_pow && A.cost0) hipLaunchKernelGGL((k_trace_wide<0, false, true, true>), g, b, RT_LEAF_COMPACT ? wide_waves() * RT_PK_LDS_WORDS * 4u : 0u, st, S, A);
-            else if (SRC == 0 && S.packet && !S.generic_pow) hipLaunchKernelGGL((k_trace_wide<0, false, true>), g, b, RT_LEAF_COMPACT ? wide_waves() * RT_PK_LDS_WORDS * 4u : 0u, st, S, A);
+            b = dim3(64u * wide_waves_of(A));
+            g = dim3((g.x + wide_waves_of(A) - 1u) / wide_waves_of(A));
+            if (SRC == 0 && S.packet && !S.generic_pow && A.cost0) hipLaunchKernelGGL((k_trace_wide<0, false, true, true>), g, b, RT_LEAF_COMPACT ? wide_waves_of(A) * RT_PK_LDS_WORDS * 4u : 0u, st, S, A);
+            else if (SRC == 0 && S.packet && !S.generic_pow) hipLaunchKernelGGL((k_trace_wide<0, false, true>), g, b, RT_LEAF_COMPACT ? wide_waves_of(A) * RT_PK_LDS_WORDS * 4u : 0u, st, S, A);
             else if (S.generic_pow) hipLaunchKernelGGL((k_trace_wide<SRC, true>), g, b, 0, st, S, A);
             else hipLaunchKernelGGL((k_trace_wide<SRC, false>), g, b, 0, st, S, A);
         }
@@ -2727,10 +2733,10 @@ void launch_extend(int src, int form, bool count, const DScene& S, const LevelAr
 template <bool COUNT, bool GPOW>
 static void launch_shade_t(int form, const DScene& S, const LevelArgs& A, dim3 g, dim3 b, hipStream_t st) {
     if (form == RT_FORM_WIDE) {
-        b = dim3(64u * wide_waves());
-        g = dim3((g.x + wide_waves() - 1u) / wide_waves());
+        b = dim3(64u * wide_waves_of(A));
+        g = dim3((g.x + wide_waves_of(A) - 1u) / wide_waves_of(A));
         // the hits of primary rays: their shadow rays are coherent too (rt_trace's caller-supplied rays need not be)
-        const uint32_t pk_lds = RT_LEAF_COMPACT ? wide_waves() * RT_PK_LDS_WORDS * 4u : 0u;
+        const uint32_t pk_lds = RT_LEAF_COMPACT ? wide_waves_of(A) * RT_PK_LDS_WORDS * 4u : 0u;
         if (S.packet && (A.level == 0 || S.packet >= 2) && (!A.user_rays || S.user_packet)) {
             if (!COUNT && !GPOW && A.level == 0 && A.level_hi == 0 && A.cost0) hipLaunchKernelGGL((k_shade_wide<false, false, true, 2>), g, b, pk_lds, st, S, A);      // expensive groups first
             else if (!COUNT && !GPOW && A.level == 0 && A.level_hi == 0) hipLaunchKernelGGL((k_shade_wide<false, false, true, 1>), g, b, pk_lds, st, S, A);

@@ -130,6 +130,7 @@ struct LevelArgs {
     const uint32_t* order0;      // level-0 per-lane launches of a small one-pass frame: wave w takes group order0[w] - the groups in
                                  // descending order of what they cost in the previous frame (k_order_groups); null: group w
     uint32_t* cost0;             // ... and every wave leaves here how long its group took (10-ns ticks), for the next frame's order
+    uint32_t wide_waves;         // waves per workgroup of the per-lane launches of this pass (0: the process default, one)
     const uint32_t* perm;        // k_shade_wide as packets over levels >= 1: the hits of the range sorted by position (launch_sort_hits),
     uint32_t perm_n;             // perm_n slots (a multiple of 64; 0xFFFFFFFF = no entry); null: pool order
     PixelMap pm;
