@@ -1029,7 +1029,9 @@ static int enqueue_passes(FrameJob& J, uint64_t px0, uint64_t npx, uint32_t pass
         // shadows-only bunny (no bounce levels) 0.206 -> 0.213.
         // (A single frame of the 10 M-triangle field at 1080p 4 spp, 8.3 M samples: 4.63 -> 5.03 ms with four - hence up to 4 M samples;
         // a rank's eighth of ten tiled frames, 2.6 M: 0.0503 -> 0.0484 ms per frame.)
-        A.wide_waves = (s->knobs.wide_waves_small > 0 && s->has_bounce && meshes && !serve && A.n0 <= (4u << 20)) ? uint32_t(s->knobs.wide_waves_small) : 0u;
+        // (levels > 0: what four waves per workgroup buy is the bounce levels' share of the chip beside level 0's light loops - a
+        // frame without bounce levels, or rendered at depth 0, is 2-4 % slower with them)
+        A.wide_waves = (s->knobs.wide_waves_small > 0 && levels > 0 && meshes && !serve && A.n0 <= (4u << 20)) ? uint32_t(s->knobs.wide_waves_small) : 0u;
         const bool split_small = s->knobs.split_small != 0;
         auto shade_small_run = [&](int lo, int hi, int after) -> int {
             // (not where the per-lane kernels traverse meshes as packets at every level: the rays of a small bounce level

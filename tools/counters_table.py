@@ -35,7 +35,7 @@ def frames_of(rows, id_key, name_key):
 
 res = {"depth0": collections.defaultdict(lambda: collections.defaultdict(float)),
        "frame": collections.defaultdict(lambda: collections.defaultdict(float))}
-WHICH = {1: "depth0", 3: "frame"}      # (frames_for_counters.py: full, depth 0, full, full)
+WHICH = {2: "depth0", 4: "frame"}      # (frames_for_counters.py: full, full, depth 0, full, full)
 for p in ("sq1", "sq2", "fetch", "write", "tcc"):
     f = glob.glob(f'gpurun_out/ctr_{p}/**/p_counter_collection.csv', recursive=True)
     if not f:

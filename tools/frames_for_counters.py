@@ -1,7 +1,9 @@
 """Target program of tools/collect_counters.sh: renders, one call per frame on the scene's stream,
-    1 full frame, 1 frame at max_depth 0, 2 full frames (a frame is scheduled by the level sizes of the frame before it:
-    the first after the depth-0 frame sees empty bounce levels, the second is the steady state that is counted).
-A frame starts with one k_set_frame_params launch, so tools/counters_table.py finds frames 2 and 4 by counting those.
+    2 full frames, 1 frame at max_depth 0, 2 full frames (a frame is scheduled by the level sizes of the frame before it:
+    the first after the depth-0 frame sees empty bounce levels, the second is the steady state that is counted; and the
+    level-0 launches of a small frame follow the order made TWO frames earlier - expensive groups first - so the depth-0
+    frame needs two frames of its size before it to be the launch bench.py times).
+A frame starts with one k_set_frame_params launch, so tools/counters_table.py finds frames 3 and 5 by counting those.
 At max_depth 0 a frame runs exactly its level-0 launches, one per kernel: their counters are PER LAUNCH."""
 import os
 import sys
@@ -18,6 +20,6 @@ p0 = Params(background=tuple(p.c.background), max_depth=0, aa=p.aa)
 dev = DeviceScene(fs)
 frame = torch.zeros((cam.imHeight, cam.imWidth, 3), dtype=torch.uint8, device="cuda")
 torch.cuda.synchronize()
-for prm in (p, p0, p, p):
+for prm in (p, p, p0, p, p):
     dev.render_device(cam, prm, frame.data_ptr())
     dev.status()
